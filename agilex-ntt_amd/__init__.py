@@ -1,0 +1,226 @@
+"""agilex-ntt_amd: MI355X-native batched negacyclic NTT engine -- thin Python host layer.
+
+The product is the C-ABI shared library ``lib/libagxntt.so`` (``include/agx_ntt.h``), built
+from ``csrc/`` by hipcc for gfx950.  This module only binds that ABI with ctypes so that
+bench.py and the tests can drive it from Python with torch providing device memory and
+streams.  There is no CPU fallback: if the library is missing, loading fails loudly.
+
+The directory name has a hyphen (it mirrors the reference repository's name), so import it
+through the ``agilex_ntt_amd`` shim at the repository root.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libagxntt.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+AGX_OK = 0
+VARIANT_AUTO, VARIANT_LDS_RADIX2, VARIANT_REGBLOCK = 0, 1, 2
+
+_u64 = ctypes.c_uint64
+_u32 = ctypes.c_uint32
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_vp = ctypes.c_void_p
+_p64 = ctypes.POINTER(ctypes.c_uint64)
+
+# name -> (restype, argtypes): every symbol include/agx_ntt.h declares
+ABI = {
+    "agx_ntt_strerror": (ctypes.c_char_p, [_int]),
+    "agx_ntt_last_hip_error": (_int, []),
+    "agx_ntt_device_count": (_int, [ctypes.POINTER(_int)]),
+    "agx_ntt_forward_host": (_int, [_p64, _p64, _p64, _p64, _p64, _p64, _u32, _u32]),
+    "agx_ntt_plan_create": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64, _p64, _p64, _p64]),
+    "agx_ntt_plan_create_auto": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64]),
+    "agx_ntt_plan_destroy": (_int, [_vp]),
+    "agx_ntt_plan_set_variant": (_int, [_vp, _int]),
+    "agx_ntt_plan_info": (_int, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "agx_ntt_plan_get_modulus": (_int, [_vp, _u32, _p64, _p64]),
+    "agx_ntt_forward": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "agx_ntt_inverse": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "agx_ntt_forward_strided": (_int, [_vp, _vp, _vp, _u64, _i64, _i64, _vp]),
+    "agx_ntt_inverse_strided": (_int, [_vp, _vp, _vp, _u64, _i64, _i64, _vp]),
+    "agx_ntt_pointwise": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
+    "agx_ntt_polymul": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp]),
+    "agx_ntt_fill_synthetic": (_int, [_vp, _vp, _u64, _u64, _u64, _vp]),
+    "agx_ntt_find_primes": (_int, [_u32, _u32, _u32, _p64]),
+    "agx_ntt_min_root": (_int, [_u64, _u32, _p64]),
+    "agx_ntt_make_tables": (_int, [_u64, _u64, _u32, _p64, _p64]),
+    "agx_ntt_make_inverse_tables": (_int, [_u64, _u64, _u32, _p64, _p64]),
+}
+
+
+class AgxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib().agx_ntt_strerror(status).decode()
+        super().__init__(f"{where}: agx status {status} ({msg}), hip error {lib().agx_ntt_last_hip_error()}")
+
+
+def build(verbose=False):
+    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _HERE, "build"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libagxntt.so.  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make -C {_HERE} build` (or __graft_entry__.build())")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(status, where):
+    if status != AGX_OK:
+        raise AgxError(status, where)
+
+
+def _np_ptr(a):
+    import numpy as np
+
+    assert isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_p64)
+
+
+def device_count():
+    c = _int(0)
+    _check(lib().agx_ntt_device_count(ctypes.byref(c)), "device_count")
+    return c.value
+
+
+# ---------------------------------------------------------------------------------------
+# host math
+# ---------------------------------------------------------------------------------------
+def find_primes(bits, n, count=1):
+    import numpy as np
+
+    out = np.zeros(count, dtype=np.uint64)
+    _check(lib().agx_ntt_find_primes(bits, n, count, _np_ptr(out)), "find_primes")
+    return [int(v) for v in out]
+
+
+def min_root(q, n):
+    r = _u64(0)
+    _check(lib().agx_ntt_min_root(q, n, ctypes.byref(r)), "min_root")
+    return r.value
+
+
+def make_tables(q, psi, n, inverse=False):
+    import numpy as np
+
+    tw = np.zeros(n, dtype=np.uint64)
+    pre = np.zeros(n, dtype=np.uint64)
+    fn = lib().agx_ntt_make_inverse_tables if inverse else lib().agx_ntt_make_tables
+    _check(fn(q, psi, n, _np_ptr(tw), _np_ptr(pre)), "make_tables")
+    return tw, pre
+
+
+# ---------------------------------------------------------------------------------------
+# one-shot host path: the reference's ntt_input_kernel + fwd_ntt_kernel + ntt_output_kernel
+# ---------------------------------------------------------------------------------------
+def forward_host(in1, in2, modulus, twiddles, precons, n, num_frames):
+    import numpy as np
+
+    out = np.zeros(num_frames * n, dtype=np.uint64)
+    mod = np.array([modulus], dtype=np.uint64)
+    _check(lib().agx_ntt_forward_host(_np_ptr(in1), _np_ptr(in2), _np_ptr(mod), _np_ptr(twiddles), _np_ptr(precons),
+                                      _np_ptr(out), n, num_frames), "forward_host")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# plans and device-pointer calls (pointers are plain integers, e.g. torch.Tensor.data_ptr())
+# ---------------------------------------------------------------------------------------
+class Plan:
+    """Device-resident tables for `moduli` at size n.  Tables are generated by the library
+    unless `tables=(tw, pre[, itw, ipre])` (each [num_primes, n] uint64) is given."""
+
+    def __init__(self, n, moduli, psi=None, tables=None):
+        import numpy as np
+
+        self.n = int(n)
+        self.moduli = [int(q) for q in moduli]
+        mods = np.array(self.moduli, dtype=np.uint64)
+        self._h = _vp(None)
+        if tables is None:
+            psi_arr = None if psi is None else np.array([int(p) for p in psi], dtype=np.uint64)
+            _check(lib().agx_ntt_plan_create_auto(ctypes.byref(self._h), self.n, len(self.moduli), _np_ptr(mods),
+                                                  None if psi_arr is None else _np_ptr(psi_arr)), "plan_create_auto")
+        else:
+            tw, pre = (np.ascontiguousarray(t, dtype=np.uint64) for t in tables[:2])
+            itw = ipre = None
+            if len(tables) == 4:
+                itw, ipre = (np.ascontiguousarray(t, dtype=np.uint64) for t in tables[2:])
+            _check(lib().agx_ntt_plan_create(ctypes.byref(self._h), self.n, len(self.moduli), _np_ptr(mods), _np_ptr(tw),
+                                             _np_ptr(pre), None if itw is None else _np_ptr(itw),
+                                             None if ipre is None else _np_ptr(ipre)), "plan_create")
+
+    @property
+    def num_primes(self):
+        return len(self.moduli)
+
+    def psi(self, k):
+        q, r = _u64(0), _u64(0)
+        _check(lib().agx_ntt_plan_get_modulus(self._h, k, ctypes.byref(q), ctypes.byref(r)), "plan_get_modulus")
+        return r.value
+
+    def set_variant(self, variant):
+        _check(lib().agx_ntt_plan_set_variant(self._h, variant), "plan_set_variant")
+
+    def forward(self, d_in, d_out, batch, stream=0):
+        _check(lib().agx_ntt_forward(self._h, d_in, d_out, batch, stream), "forward")
+
+    def inverse(self, d_in, d_out, batch, stream=0):
+        _check(lib().agx_ntt_inverse(self._h, d_in, d_out, batch, stream), "inverse")
+
+    def forward_strided(self, d_in, d_out, batch, prime_stride, poly_stride, stream=0):
+        _check(lib().agx_ntt_forward_strided(self._h, d_in, d_out, batch, prime_stride, poly_stride, stream), "forward_strided")
+
+    def inverse_strided(self, d_in, d_out, batch, prime_stride, poly_stride, stream=0):
+        _check(lib().agx_ntt_inverse_strided(self._h, d_in, d_out, batch, prime_stride, poly_stride, stream), "inverse_strided")
+
+    def pointwise(self, d_a, d_b, d_c, batch, stream=0):
+        _check(lib().agx_ntt_pointwise(self._h, d_a, d_b, d_c, batch, stream), "pointwise")
+
+    def polymul(self, d_a, d_b, d_c, d_scratch, batch, stream=0):
+        _check(lib().agx_ntt_polymul(self._h, d_a, d_b, d_c, d_scratch, batch, stream), "polymul")
+
+    def fill_synthetic(self, d_out, batch, first_poly=0, seed=42, stream=0):
+        _check(lib().agx_ntt_fill_synthetic(self._h, d_out, batch, first_poly, seed, stream), "fill_synthetic")
+
+    def close(self):
+        if self._h:
+            lib().agx_ntt_plan_destroy(self._h)
+            self._h = _vp(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------
+# sharding of independent frames over ranks (no collective on the data path)
+# ---------------------------------------------------------------------------------------
+def shard_range(total, rank, world):
+    """Contiguous block [lo, hi) of `total` polynomials owned by `rank` of `world`."""
+    lo = total * rank // world
+    hi = total * (rank + 1) // world
+    return lo, hi

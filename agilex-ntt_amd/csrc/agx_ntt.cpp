@@ -1,0 +1,381 @@
+// agx_ntt.cpp -- the extern "C" boundary declared in include/agx_ntt.h.
+// Owns argument validation, plan objects (device tables) and the mapping of HIP errors to
+// status codes.  Kernels live in ntt_kernels.hip; number theory in host_math.cpp.
+#include "../../include/agx_ntt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "host_math.hpp"
+#include "ntt_kernels.hpp"
+
+using namespace agx;
+
+struct agx_ntt_plan {
+    uint32_t n = 0, log_n = 0, num_primes = 0;
+    int device = -1;
+    int variant = AGX_VARIANT_AUTO;
+    bool has_inverse = false;
+    std::vector<uint64_t> moduli, psi;  // psi = 0 when the tables came from the caller
+    prime_consts* d_consts = nullptr;
+    ulonglong2* d_tw = nullptr;
+    ulonglong2* d_itw = nullptr;
+    ulonglong2* d_tw_rb = nullptr;
+    regblock_layout rb;
+};
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+int hip_fail(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return e == hipErrorOutOfMemory ? AGX_ERR_ALLOC : AGX_ERR_HIP;
+}
+
+#define AGX_HIP(expr)                                    \
+    do {                                                 \
+        hipError_t e_ = (expr);                          \
+        if (e_ != hipSuccess) return hip_fail(e_);       \
+    } while (0)
+
+int check_size(uint32_t n) {
+    return (n >= AGX_NTT_MIN_N && n <= AGX_NTT_MAX_N && is_pow2(n)) ? AGX_OK : AGX_ERR_BAD_SIZE;
+}
+
+// what the butterfly arithmetic needs (src/kernel/ntt.cpp:302-369): 4q < 2^64 and 2n | q-1
+int check_modulus(uint64_t q, uint32_t n) {
+    if (q < 3 || (q & 1) == 0 || q >= (1ull << 62)) return AGX_ERR_BAD_MODULUS;
+    if ((q - 1) % (2ull * n)) return AGX_ERR_BAD_MODULUS;
+    return AGX_OK;
+}
+
+plan_view view_of(const agx_ntt_plan* p) {
+    plan_view v;
+    v.n = p->n;
+    v.log_n = p->log_n;
+    v.num_primes = p->num_primes;
+    v.consts = p->d_consts;
+    v.tw = p->d_tw;
+    v.itw = p->d_itw;
+    v.rb = p->rb;
+    v.tw_rb = p->d_tw_rb;
+    return v;
+}
+
+void free_plan(agx_ntt_plan* p) {
+    if (!p) return;
+    if (p->d_consts) (void)hipFree(p->d_consts);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_itw) (void)hipFree(p->d_itw);
+    if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
+    delete p;
+}
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src) {
+    AGX_HIP(hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(T)));
+    AGX_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return AGX_OK;
+}
+
+// n^-1 mod q for odd q and n a power of two: ((q+1)/2)^log2(n)
+uint64_t inv_pow2_mod(uint32_t log_n, uint64_t q) {
+    const uint64_t half = (q + 1) >> 1;
+    uint64_t r = 1 % q;
+    for (uint32_t i = 0; i < log_n; ++i) r = mul_mod(r, half, q);
+    return r;
+}
+
+int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64_t* moduli, const uint64_t* psi,
+               const uint64_t* tw, const uint64_t* pre, const uint64_t* itw, const uint64_t* ipre) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AGX_ERR_NO_DEVICE;
+    agx_ntt_plan* p = new (std::nothrow) agx_ntt_plan;
+    if (!p) return AGX_ERR_ALLOC;
+    p->n = n;
+    p->log_n = (uint32_t)log2u(n);
+    p->num_primes = num_primes;
+    p->has_inverse = itw != nullptr;
+    p->moduli.assign(moduli, moduli + num_primes);
+    p->psi.assign(num_primes, 0);
+    if (psi) p->psi.assign(psi, psi + num_primes);
+    int rc = AGX_OK;
+    hipError_t he = hipGetDevice(&p->device);
+    if (he == hipSuccess) he = kernels_init();
+    if (he != hipSuccess) { free_plan(p); return hip_fail(he); }
+
+    std::vector<prime_consts> consts(num_primes);
+    std::vector<ulonglong2> tw_pairs((size_t)num_primes * n), itw_pairs;
+    if (itw) itw_pairs.resize((size_t)num_primes * n);
+    p->rb = regblock_choose(n);
+    std::vector<ulonglong2> rb_pairs;
+    for (uint32_t k = 0; k < num_primes; ++k) {
+        const uint64_t q = moduli[k];
+        prime_consts& c = consts[k];
+        std::memset(&c, 0, sizeof(c));
+        c.q = q;
+        const unsigned __int128 mu = ~(unsigned __int128)0 / q;  // = floor(2^128 / q) for odd q > 1
+        c.mu_hi = (uint64_t)(mu >> 64);
+        c.mu_lo = (uint64_t)mu;
+        c.n_inv = inv_pow2_mod(p->log_n, q);
+        c.n_inv_p = shoup_quotient(c.n_inv, q);
+        const uint64_t* twk = tw + (size_t)k * n;
+        const uint64_t* prek = pre + (size_t)k * n;
+        for (uint32_t j = 0; j < n; ++j) tw_pairs[(size_t)k * n + j] = make_ulonglong2(twk[j], prek[j]);
+        if (itw) {
+            const uint64_t* itwk = itw + (size_t)k * n;
+            const uint64_t* iprek = ipre + (size_t)k * n;
+            for (uint32_t j = 0; j < n; ++j) itw_pairs[(size_t)k * n + j] = make_ulonglong2(itwk[j], iprek[j]);
+            c.w1n = mul_mod(itwk[1] % q, c.n_inv, q);
+            c.w1n_p = shoup_quotient(c.w1n, q);
+        }
+        if (p->rb.valid()) regblock_build_table(p->rb, twk, prek, rb_pairs);
+    }
+    if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
+    if ((rc = upload(&p->d_tw, tw_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (itw && (rc = upload(&p->d_itw, itw_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (p->rb.valid() && (rc = upload(&p->d_tw_rb, rb_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    *out = p;
+    return AGX_OK;
+}
+
+int check_call(const agx_ntt_plan* plan, const void* a, const void* b, uint64_t batch, int64_t prime_stride, int64_t poly_stride) {
+    if (!plan || !a || !b) return AGX_ERR_NULL_POINTER;
+    if (prime_stride < 0 || poly_stride < 0) return AGX_ERR_BAD_ARGUMENT;
+    if (batch > 0 && poly_stride < (int64_t)plan->n && batch > 1) return AGX_ERR_BAD_ARGUMENT;
+    if ((batch << (plan->log_n > 14 ? plan->log_n - 14 : 0)) > 0x7fffffffull) return AGX_ERR_BAD_ARGUMENT;  // grid.x limit
+    return AGX_OK;
+}
+
+bool use_regblock(const agx_ntt_plan* plan) {
+    if (plan->variant == AGX_VARIANT_LDS_RADIX2) return false;
+    return plan->rb.valid();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* agx_ntt_strerror(int status) {
+    switch (status) {
+        case AGX_OK: return "success";
+        case AGX_ERR_NULL_POINTER: return "required pointer argument is NULL";
+        case AGX_ERR_BAD_SIZE: return "n must be a power of two in [2, 32768]";
+        case AGX_ERR_BAD_MODULUS: return "modulus must be an odd prime < 2^62 with q = 1 (mod 2n)";
+        case AGX_ERR_BAD_ROOT: return "psi is not a primitive 2n-th root of unity mod q";
+        case AGX_ERR_BAD_ARGUMENT: return "invalid argument";
+        case AGX_ERR_NO_DEVICE: return "no HIP device available";
+        case AGX_ERR_HIP: return "HIP runtime error (see agx_ntt_last_hip_error)";
+        case AGX_ERR_ALLOC: return "allocation failed";
+        case AGX_ERR_NO_INVERSE: return "plan has no inverse tables";
+    }
+    return "unknown status";
+}
+
+int agx_ntt_last_hip_error(void) { return g_last_hip_error; }
+
+int agx_ntt_device_count(int* count) {
+    if (!count) return AGX_ERR_NULL_POINTER;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return AGX_OK;
+}
+
+int agx_ntt_plan_create(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, const uint64_t* moduli,
+                        const uint64_t* twiddles, const uint64_t* precons,
+                        const uint64_t* inv_twiddles, const uint64_t* inv_precons) {
+    if (!plan || !moduli || !twiddles || !precons) return AGX_ERR_NULL_POINTER;
+    *plan = nullptr;
+    if ((inv_twiddles == nullptr) != (inv_precons == nullptr)) return AGX_ERR_NULL_POINTER;
+    int rc = check_size(n);
+    if (rc) return rc;
+    if (num_primes == 0 || num_primes > 65535) return AGX_ERR_BAD_ARGUMENT;
+    for (uint32_t k = 0; k < num_primes; ++k)
+        if ((rc = check_modulus(moduli[k], n))) return rc;
+    return build_plan(plan, n, num_primes, moduli, nullptr, twiddles, precons, inv_twiddles, inv_precons);
+}
+
+int agx_ntt_plan_create_auto(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, const uint64_t* moduli, const uint64_t* psi) {
+    if (!plan || !moduli) return AGX_ERR_NULL_POINTER;
+    *plan = nullptr;
+    int rc = check_size(n);
+    if (rc) return rc;
+    if (num_primes == 0 || num_primes > 65535) return AGX_ERR_BAD_ARGUMENT;
+    std::vector<uint64_t> roots(num_primes), tw((size_t)num_primes * n), pre(tw.size()), itw(tw.size()), ipre(tw.size());
+    for (uint32_t k = 0; k < num_primes; ++k) {
+        const uint64_t q = moduli[k];
+        if ((rc = check_modulus(q, n))) return rc;
+        if (!is_prime_u64(q)) return AGX_ERR_BAD_MODULUS;
+        roots[k] = psi ? psi[k] : min_primitive_root_2n(q, n);
+        if (!is_primitive_root_2n(roots[k], q, n)) return AGX_ERR_BAD_ROOT;
+        power_tables_bitrev(q, roots[k], n, &tw[(size_t)k * n], &pre[(size_t)k * n]);
+        power_tables_bitrev(q, inv_mod(roots[k], q), n, &itw[(size_t)k * n], &ipre[(size_t)k * n]);
+    }
+    return build_plan(plan, n, num_primes, moduli, roots.data(), tw.data(), pre.data(), itw.data(), ipre.data());
+}
+
+int agx_ntt_plan_destroy(agx_ntt_plan* plan) {
+    free_plan(plan);
+    return AGX_OK;
+}
+
+int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant) {
+    if (!plan) return AGX_ERR_NULL_POINTER;
+    if (variant != AGX_VARIANT_AUTO && variant != AGX_VARIANT_LDS_RADIX2 && variant != AGX_VARIANT_REGBLOCK) return AGX_ERR_BAD_ARGUMENT;
+    if (variant == AGX_VARIANT_REGBLOCK && !plan->rb.valid()) return AGX_ERR_BAD_SIZE;
+    plan->variant = variant;
+    return AGX_OK;
+}
+
+int agx_ntt_plan_info(const agx_ntt_plan* plan, uint32_t* n, uint32_t* num_primes, int* device, int* has_inverse) {
+    if (!plan) return AGX_ERR_NULL_POINTER;
+    if (n) *n = plan->n;
+    if (num_primes) *num_primes = plan->num_primes;
+    if (device) *device = plan->device;
+    if (has_inverse) *has_inverse = plan->has_inverse ? 1 : 0;
+    return AGX_OK;
+}
+
+int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uint64_t* q, uint64_t* psi) {
+    if (!plan) return AGX_ERR_NULL_POINTER;
+    if (prime_index >= plan->num_primes) return AGX_ERR_BAD_ARGUMENT;
+    if (q) *q = plan->moduli[prime_index];
+    if (psi) *psi = plan->psi[prime_index];
+    return AGX_OK;
+}
+
+int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
+                            int64_t prime_stride, int64_t poly_stride, void* stream) {
+    int rc = check_call(plan, d_in, d_out, batch, prime_stride, poly_stride);
+    if (rc) return rc;
+    if (batch == 0) return AGX_OK;
+    const frame_layout fl{batch, prime_stride, poly_stride};
+    const plan_view pv = view_of(plan);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    AGX_HIP(use_regblock(plan) ? launch_forward_regblock(pv, d_in, d_out, fl, s) : launch_forward_radix2(pv, d_in, d_out, fl, s));
+    return AGX_OK;
+}
+
+int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
+                            int64_t prime_stride, int64_t poly_stride, void* stream) {
+    int rc = check_call(plan, d_in, d_out, batch, prime_stride, poly_stride);
+    if (rc) return rc;
+    if (!plan->has_inverse) return AGX_ERR_NO_INVERSE;
+    if (batch == 0) return AGX_OK;
+    const frame_layout fl{batch, prime_stride, poly_stride};
+    AGX_HIP(launch_inverse_radix2(view_of(plan), d_in, d_out, fl, static_cast<hipStream_t>(stream)));
+    return AGX_OK;
+}
+
+int agx_ntt_forward(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream) {
+    if (!plan) return AGX_ERR_NULL_POINTER;
+    return agx_ntt_forward_strided(plan, d_in, d_out, batch, (int64_t)(batch * plan->n), (int64_t)plan->n, stream);
+}
+
+int agx_ntt_inverse(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream) {
+    if (!plan) return AGX_ERR_NULL_POINTER;
+    return agx_ntt_inverse_strided(plan, d_in, d_out, batch, (int64_t)(batch * plan->n), (int64_t)plan->n, stream);
+}
+
+int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c, uint64_t batch, void* stream) {
+    if (!plan || !d_a || !d_b || !d_c) return AGX_ERR_NULL_POINTER;
+    if (batch == 0) return AGX_OK;
+    AGX_HIP(launch_pointwise(view_of(plan), d_a, d_b, d_c, batch, static_cast<hipStream_t>(stream)));
+    return AGX_OK;
+}
+
+int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
+                    uint64_t* d_scratch, uint64_t batch, void* stream) {
+    if (!plan || !d_a || !d_b || !d_c || !d_scratch) return AGX_ERR_NULL_POINTER;
+    if (d_scratch == d_a || d_scratch == d_b || d_scratch == d_c) return AGX_ERR_BAD_ARGUMENT;
+    if (!plan->has_inverse) return AGX_ERR_NO_INVERSE;
+    int rc;
+    // scratch <- NTT(a); c <- NTT(b) (a is dead by now, so c may alias it); c <- c o scratch; c <- INTT(c)
+    if ((rc = agx_ntt_forward(plan, d_a, d_scratch, batch, stream))) return rc;
+    if ((rc = agx_ntt_forward(plan, d_b, d_c, batch, stream))) return rc;
+    if ((rc = agx_ntt_pointwise(plan, d_c, d_scratch, d_c, batch, stream))) return rc;
+    return agx_ntt_inverse(plan, d_c, d_c, batch, stream);
+}
+
+int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t batch, uint64_t first_poly, uint64_t seed, void* stream) {
+    if (!plan || !d_out) return AGX_ERR_NULL_POINTER;
+    if (batch == 0) return AGX_OK;
+    AGX_HIP(launch_fill(view_of(plan), d_out, batch, first_poly, seed, static_cast<hipStream_t>(stream)));
+    return AGX_OK;
+}
+
+int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
+                         const uint64_t* twiddles, const uint64_t* precons, uint64_t* out,
+                         uint32_t n, uint32_t num_frames) {
+    if (!in || !in2 || !modulus || !twiddles || !precons || !out) return AGX_ERR_NULL_POINTER;
+    int rc = check_size(n);
+    if (rc) return rc;
+    if ((rc = check_modulus(modulus[0], n))) return rc;
+    if (num_frames == 0) return AGX_OK;
+    agx_ntt_plan* plan = nullptr;
+    if ((rc = build_plan(&plan, n, 1, modulus, nullptr, twiddles, precons, nullptr, nullptr))) return rc;
+    uint64_t* d = nullptr;
+    const size_t row = (size_t)n * sizeof(uint64_t), half = row / 2;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), row * num_frames);
+    // frame b = in[b*n .. +n/2) || in2[b*n + n/2 .. +n/2)      (src/kernel/ntt.cpp:584-590)
+    if (e == hipSuccess) e = hipMemcpy2D(d, row, in, row, half, num_frames, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy2D(reinterpret_cast<char*>(d) + half, row, reinterpret_cast<const char*>(in2) + half, row, half, num_frames, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = agx_ntt_forward(plan, d, d, num_frames, nullptr);
+        if (rc == AGX_OK) e = hipMemcpy(out, d, row * num_frames, hipMemcpyDeviceToHost);  // src/kernel/ntt.cpp:628-633
+    }
+    if (d) (void)hipFree(d);
+    free_plan(plan);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e);
+    return AGX_OK;
+}
+
+int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t* primes_out) {
+    if (!primes_out) return AGX_ERR_NULL_POINTER;
+    int rc = check_size(n);
+    if (rc) return rc;
+    if (bits < 2 || bits > 62) return AGX_ERR_BAD_ARGUMENT;
+    std::vector<uint64_t> v = find_ntt_primes(bits, n, count);
+    if (v.size() < count) return AGX_ERR_BAD_ARGUMENT;
+    std::memcpy(primes_out, v.data(), sizeof(uint64_t) * count);
+    return AGX_OK;
+}
+
+int agx_ntt_min_root(uint64_t q, uint32_t n, uint64_t* psi_out) {
+    if (!psi_out) return AGX_ERR_NULL_POINTER;
+    int rc = check_size(n);
+    if (rc) return rc;
+    if ((rc = check_modulus(q, n))) return rc;
+    if (!is_prime_u64(q)) return AGX_ERR_BAD_MODULUS;
+    const uint64_t r = min_primitive_root_2n(q, n);
+    if (!r) return AGX_ERR_BAD_ROOT;
+    *psi_out = r;
+    return AGX_OK;
+}
+
+static int make_tables_common(uint64_t q, uint64_t psi, uint32_t n, uint64_t* tw, uint64_t* pre, bool inverse) {
+    if (!tw || !pre) return AGX_ERR_NULL_POINTER;
+    int rc = check_size(n);
+    if (rc) return rc;
+    if ((rc = check_modulus(q, n))) return rc;
+    if (!is_prime_u64(q)) return AGX_ERR_BAD_MODULUS;
+    if (!is_primitive_root_2n(psi, q, n)) return AGX_ERR_BAD_ROOT;
+    power_tables_bitrev(q, inverse ? inv_mod(psi, q) : psi, n, tw, pre);
+    return AGX_OK;
+}
+
+int agx_ntt_make_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* twiddles, uint64_t* precons) {
+    return make_tables_common(q, psi, n, twiddles, precons, false);
+}
+
+int agx_ntt_make_inverse_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* inv_twiddles, uint64_t* inv_precons) {
+    return make_tables_common(q, psi, n, inv_twiddles, inv_precons, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,518 @@
+// ntt_kernels.hip -- gfx950 (CDNA4, wave64) kernels for the batched negacyclic NTT.
+//
+// Two families:
+//  * radix-2 / LDS-resident kernels: one workgroup per frame, one butterfly stage per barrier.
+//    They perform exactly the reference's operation sequence (src/kernel/ntt.cpp:147-180,
+//    298-300, 331-369, 377-394), so they are bit-identical to it even on out-of-contract
+//    tables.  Any power-of-two n; used for small n, as the always-available fallback and
+//    for the inverse transform.
+//  * register-blocked kernels: every thread keeps 2^R coefficients in VGPRs and runs R
+//    butterfly stages per pass with no memory traffic; passes exchange through one padded
+//    LDS slab.  This is the throughput path (n >= 1024).
+//
+// No MFMA: this is 64-bit integer modular arithmetic (v_mad_u64_u32 / v_mul_hi_u32), bounded
+// by VALU integer multiply issue and HBM bandwidth.
+#include "ntt_kernels.hpp"
+#include "modarith.hpp"
+
+#include <type_traits>
+#include <utility>
+
+namespace agx {
+
+static constexpr int kMaxLdsLog = 14;  // 16384 coefficients = 128 KiB of the CU's 160 KiB LDS
+
+// ---------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------
+template <int B, int E, typename F>
+__device__ __host__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(std::forward<F>(f));
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char agx_dyn_lds[];
+
+// ---------------------------------------------------------------------------------------
+// radix-2 forward, LDS resident.  Block = one sub-transform of 2^nb_log coefficients:
+// sub-block `blk` of the 2^split_log contiguous blocks a frame falls into after the first
+// split_log stages (done by fwd_global_stage).  split_log = 0 -> the whole frame.
+// ---------------------------------------------------------------------------------------
+__global__ void fwd_radix2_lds(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                               const prime_consts* __restrict__ consts, const twpair* __restrict__ tw,
+                               uint32_t log_n, uint32_t nb_log, uint32_t split_log,
+                               int64_t prime_stride, int64_t poly_stride) {
+    uint64_t* x = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    const uint32_t nb = 1u << nb_log;
+    const uint32_t prime = blockIdx.y;
+    const uint64_t poly = blockIdx.x >> split_log;
+    const uint32_t blk = blockIdx.x & ((1u << split_log) - 1u);
+    const uint64_t q = consts[prime].q, q2 = q << 1;
+    const twpair* twp = tw + ((size_t)prime << log_n);
+    const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)blk << nb_log);
+
+    for (uint32_t e = threadIdx.x; e < nb; e += blockDim.x) x[e] = in[base + e];
+
+    uint32_t t_log = nb_log - 1;
+    for (uint32_t m = 1u << split_log; m < (1u << log_n); m <<= 1, --t_log) {
+        __syncthreads();
+        const uint32_t t = 1u << t_log;
+        const uint32_t m_local = m >> split_log;
+        for (uint32_t bf = threadIdx.x; bf < (nb >> 1); bf += blockDim.x) {
+            const uint32_t i = bf >> t_log, j = bf & (t - 1);
+            const uint32_t pos = (i << (t_log + 1)) + j;
+            const twpair w = twp[m + blk * m_local + i];   // ntt.cpp:298-300
+            uint64_t a = x[pos], b = x[pos + t];
+            ct_butterfly(a, b, w.x, w.y, q, q2);
+            if (t == 1) {                                    // ntt.cpp:377-394
+                a = reduce_4q(a, q, q2);
+                b = reduce_4q(b, q, q2);
+            }
+            x[pos] = a;
+            x[pos + t] = b;
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < nb; e += blockDim.x) out[base + e] = x[e];
+}
+
+// one forward stage straight through global memory (only for frames larger than the LDS slab).
+// stage s (0 = first): m = 2^s groups, gap t = n / 2^(s+1).
+__global__ void fwd_global_stage(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+                                 const prime_consts* __restrict__ consts, const twpair* __restrict__ tw,
+                                 uint32_t log_n, uint32_t stage, uint64_t batch,
+                                 int64_t prime_stride, int64_t poly_stride) {
+    const uint32_t prime = blockIdx.y;
+    const uint64_t q = consts[prime].q, q2 = q << 1;
+    const twpair* twp = tw + ((size_t)prime << log_n);
+    const uint32_t half_log = log_n - 1, t_log = log_n - 1 - stage, t = 1u << t_log, m = 1u << stage;
+    const uint64_t total = batch << half_log;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t poly = g >> half_log;
+        const uint32_t bf = (uint32_t)(g & ((1u << half_log) - 1u));
+        const uint32_t i = bf >> t_log, j = bf & (t - 1);
+        const int64_t pos = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)i << (t_log + 1)) + j;
+        const twpair w = twp[m + i];
+        uint64_t a = src[pos], b = src[pos + t];
+        ct_butterfly(a, b, w.x, w.y, q, q2);
+        if (t == 1) { a = reduce_4q(a, q, q2); b = reduce_4q(b, q, q2); }
+        dst[pos] = a;
+        dst[pos + t] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// radix-2 inverse (Gentleman-Sande), LDS resident: stages t = 1 .. nb/2 of each 2^nb_log
+// block; the remaining split_log stages (gaps >= nb) run in inv_global_stage.  The stage with
+// m = 1 also multiplies by n^-1 and fully reduces.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void gs_last(uint64_t& a, uint64_t& b, const prime_consts& k, uint64_t q2) {
+    const uint64_t s = a + b;            // < 4q: mul_shoup_lazy takes any 64-bit value
+    const uint64_t d = a + q2 - b;
+    a = csub(mul_shoup_lazy(s, k.n_inv, k.n_inv_p, k.q), k.q);
+    b = csub(mul_shoup_lazy(d, k.w1n, k.w1n_p, k.q), k.q);
+}
+
+__global__ void inv_radix2_lds(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                               const prime_consts* __restrict__ consts, const twpair* __restrict__ itw,
+                               uint32_t log_n, uint32_t nb_log, uint32_t split_log,
+                               int64_t prime_stride, int64_t poly_stride) {
+    uint64_t* x = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    const uint32_t nb = 1u << nb_log;
+    const uint32_t prime = blockIdx.y;
+    const uint64_t poly = blockIdx.x >> split_log;
+    const uint32_t blk = blockIdx.x & ((1u << split_log) - 1u);
+    const prime_consts k = consts[prime];
+    const uint64_t q = k.q, q2 = q << 1;
+    const twpair* twp = itw + ((size_t)prime << log_n);
+    const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)blk << nb_log);
+
+    for (uint32_t e = threadIdx.x; e < nb; e += blockDim.x) x[e] = csub(in[base + e], q2);  // [0,4q) -> [0,2q)
+
+    uint32_t t_log = 0;
+    for (uint32_t m = 1u << (log_n - 1); m >= (1u << split_log); m >>= 1, ++t_log) {
+        __syncthreads();
+        const uint32_t t = 1u << t_log;
+        const uint32_t m_local = m >> split_log;
+        for (uint32_t bf = threadIdx.x; bf < (nb >> 1); bf += blockDim.x) {
+            const uint32_t i = bf >> t_log, j = bf & (t - 1);
+            const uint32_t pos = (i << (t_log + 1)) + j;
+            uint64_t a = x[pos], b = x[pos + t];
+            if (m == 1) {
+                gs_last(a, b, k, q2);
+            } else {
+                const twpair w = twp[m + blk * m_local + i];
+                gs_butterfly(a, b, w.x, w.y, q, q2);
+            }
+            x[pos] = a;
+            x[pos + t] = b;
+        }
+        if (m == 1) break;
+    }
+    __syncthreads();
+    if (nb_log == 0) x[0] = csub(x[0], q);
+    for (uint32_t e = threadIdx.x; e < nb; e += blockDim.x) out[base + e] = x[e];
+}
+
+__global__ void inv_global_stage(uint64_t* __restrict__ data, const prime_consts* __restrict__ consts,
+                                 const twpair* __restrict__ itw, uint32_t log_n, uint32_t stage, uint64_t batch,
+                                 int64_t prime_stride, int64_t poly_stride) {
+    // `stage` counts like the forward pass: m = 2^stage groups, gap t = n / 2^(stage+1)
+    const uint32_t prime = blockIdx.y;
+    const prime_consts k = consts[prime];
+    const uint64_t q = k.q, q2 = q << 1;
+    const twpair* twp = itw + ((size_t)prime << log_n);
+    const uint32_t half_log = log_n - 1, t_log = log_n - 1 - stage, t = 1u << t_log, m = 1u << stage;
+    const uint64_t total = batch << half_log;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t poly = g >> half_log;
+        const uint32_t bf = (uint32_t)(g & ((1u << half_log) - 1u));
+        const uint32_t i = bf >> t_log, j = bf & (t - 1);
+        const int64_t pos = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)i << (t_log + 1)) + j;
+        uint64_t a = data[pos], b = data[pos + t];
+        if (m == 1) {
+            gs_last(a, b, k, q2);
+        } else {
+            const twpair w = twp[m + i];
+            gs_butterfly(a, b, w.x, w.y, q, q2);
+        }
+        data[pos] = a;
+        data[pos + t] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// register-blocked forward kernel.
+//
+// n = 2^L per workgroup-resident (sub-)transform, C = 2^R coefficients per thread, T = n / C
+// threads per frame, PPB frames per workgroup.  Coefficient index bits are processed from the
+// top (gap n/2) down to bit 0, R at a time:
+//   pass p keeps index bits [rlo+R-1 : rlo] in the register number r, rlo = max(L - R(p+1), 0):
+//       e(tid, r) = (tid & (2^rlo - 1)) | r << rlo | (tid >> rlo) << (rlo + R)
+//   and runs the stages whose gap bit b lies in [L-1-Rp : rlo] entirely in registers.
+// Between passes the coefficients cross threads through one LDS slab (index padded by one
+// element per 16 to spread the strided pass layouts over the banks).
+// The twiddle for registers (r0, r0 | 2^rb) at gap bit b = rlo + rb is natural index
+//   2^(L-1-b) + ((tid >> rlo) << k) + (r0 >> (rb+1)),   k = R-1-rb,
+// stored in the pass table at [(2^k + (r0 >> (rb+1))) * H + (tid >> rlo)], H = threads/2^rlo:
+// consecutive lanes read consecutive 16-byte {w,w'} pairs; in pass 0 (H = 1) the address is
+// wave-uniform and the loads are scalar.
+// ---------------------------------------------------------------------------------------
+template <int L, int R>
+struct rb_geom {
+    static constexpr int C = 1 << R;
+    static constexpr int T = 1 << (L - R);
+    static constexpr int NP = (L + R - 1) / R;
+    static constexpr int rlo(int p) { return (L - R * (p + 1)) > 0 ? (L - R * (p + 1)) : 0; }
+    static constexpr int hi(int p) { return L - 1 - R * p; }
+    static constexpr int H(int p) { return 1 << (L - R - rlo(p)); }           // distinct (tid >> rlo)
+    static constexpr int table_off(int p) { return p == 0 ? 0 : table_off(p - 1) + C * H(p - 1); }
+    static constexpr int table_pairs = table_off(NP);
+    static constexpr int lds_elems = (1 << L) + (1 << (L - 4));
+};
+
+__device__ __forceinline__ constexpr uint32_t lds_pad(uint32_t e) { return e + (e >> 4); }
+
+template <int L, int R, int PPB, bool STAGE_OUT>
+__global__ void __launch_bounds__((1 << (L - R)) * PPB)
+fwd_regblock(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+             const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
+             uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
+             int64_t prime_stride, int64_t poly_stride) {
+    using G = rb_geom<L, R>;
+    constexpr int C = G::C, T = G::T, NP = G::NP;
+    uint64_t* lds = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+
+    const uint32_t tid = threadIdx.x & (T - 1);
+    const uint32_t slot = threadIdx.x / T;
+    uint64_t fx = (uint64_t)blockIdx.x * PPB + slot;      // (poly, blk) flattened
+    const bool live = fx < frames_x;
+    if (!live) fx = frames_x - 1;                         // keep every thread on the barriers
+    const uint32_t prime = blockIdx.y;
+    const uint64_t poly = fx >> split_log;
+    const uint32_t blk = (uint32_t)(fx & ((1u << split_log) - 1u));
+    const uint64_t q = consts[prime].q, q2 = q << 1;
+    const twpair* tbl = tw_rb + (size_t)prime * pairs_per_prime;
+    const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)blk << L);
+    uint64_t* slab = lds + (size_t)slot * G::lds_elems;
+
+    uint64_t x[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) x[r] = in[base + tid + (uint32_t)r * T];
+
+    static_for<0, NP>([&](auto P) {
+        constexpr int p = P;
+        constexpr int rlo = G::rlo(p), hi = G::hi(p), H = G::H(p);
+        const uint32_t low = tid & ((1u << rlo) - 1u), high = tid >> rlo;
+        const uint32_t ebase = low | (high << (rlo + R));
+        if constexpr (p > 0) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) x[r] = slab[lds_pad(ebase | ((uint32_t)r << rlo))];
+        }
+        // column of this thread in the pass table (blk selects the sub-transform's columns)
+        const twpair* col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + (H == 1 ? 0u : high);
+        const uint32_t hstride = (uint32_t)H << split_log;
+        static_for<0, hi - rlo + 1>([&](auto S) {
+            constexpr int rb = (hi - rlo) - S;       // register bit of this stage, descending
+            constexpr int k = R - 1 - rb;
+            constexpr bool last_stage = (rlo + rb) == 0;
+#pragma unroll
+            for (int r0 = 0; r0 < C; ++r0) {
+                if ((r0 >> rb) & 1) continue;
+                const int r1 = r0 | (1 << rb);
+                const int j = (1 << k) + (r0 >> (rb + 1));
+                const twpair w = col[(size_t)j * hstride];
+                ct_butterfly(x[r0], x[r1], w.x, w.y, q, q2);
+                if constexpr (last_stage) {
+                    x[r0] = reduce_4q(x[r0], q, q2);
+                    x[r1] = reduce_4q(x[r1], q, q2);
+                }
+            }
+        });
+        if constexpr (p < NP - 1) {
+            if constexpr (p > 0) __syncthreads();   // everyone has finished reading the slab
+#pragma unroll
+            for (int r = 0; r < C; ++r) slab[lds_pad(ebase | ((uint32_t)r << rlo))] = x[r];
+            __syncthreads();
+        }
+    });
+
+    // last pass has rlo = 0: thread holds C consecutive coefficients starting at tid * C
+    if constexpr (STAGE_OUT) {
+        if constexpr (NP > 1) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < C; ++r) slab[lds_pad((tid << R) | (uint32_t)r)] = x[r];
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) out[base + tid + (uint32_t)r * T] = slab[lds_pad(tid + (uint32_t)r * T)];
+        }
+    } else if (live) {
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(out + base + ((size_t)tid << R));
+#pragma unroll
+        for (int r = 0; r < C; r += 2) o[r >> 1] = make_ulonglong2(x[r], x[r + 1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// pointwise product and synthetic fill
+// ---------------------------------------------------------------------------------------
+__global__ void pointwise_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ c,
+                                 const prime_consts* __restrict__ consts, uint64_t per_prime) {
+    const uint32_t prime = blockIdx.y;
+    const prime_consts k = consts[prime];
+    const barrett128 bk{k.q, k.mu_hi, k.mu_lo};
+    const uint64_t q2 = k.q << 1;
+    const uint64_t off = (uint64_t)prime * per_prime;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_prime; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t u = reduce_4q(a[off + i], k.q, q2), v = reduce_4q(b[off + i], k.q, q2);
+        c[off + i] = mul_mod_barrett(u, v, bk);
+    }
+}
+
+__device__ __forceinline__ uint64_t splitmix_mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// element (prime, poly, i) = mix(mix(mix(seed ^ prime) + poly) + i) mod q : counter based, so the
+// same coefficients come out whatever the sharding over devices
+__global__ void fill_kernel(uint64_t* __restrict__ out, const prime_consts* __restrict__ consts,
+                            uint32_t log_n, uint64_t batch, uint64_t first_poly, uint64_t seed) {
+    const uint32_t prime = blockIdx.y;
+    const uint64_t q = consts[prime].q;
+    const uint64_t per_prime = batch << log_n;
+    const uint64_t kp = splitmix_mix(seed ^ (uint64_t)prime);
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < per_prime; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t poly = first_poly + (g >> log_n), i = g & ((1ull << log_n) - 1ull);
+        out[(uint64_t)prime * per_prime + g] = splitmix_mix(splitmix_mix(kp + poly) + i) % q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side: table construction and launches
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct rb_config { int log_local; int r; int ppb; };
+// one tuned configuration per workgroup-resident size
+constexpr rb_config kRbConfigs[] = {
+    {10, 4, 4}, {11, 4, 2}, {12, 4, 1}, {13, 5, 1}, {14, 5, 1},
+};
+
+const rb_config* rb_find(int log_local) {
+    for (const rb_config& c : kRbConfigs)
+        if (c.log_local == log_local) return &c;
+    return nullptr;
+}
+
+template <int L, int R>
+void build_table_t(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {
+    using G = rb_geom<L, R>;
+    const uint32_t nblk = 1u << rb.log_split;
+    const size_t start = out.size();
+    out.resize(start + (size_t)G::table_pairs * nblk, make_ulonglong2(0, 0));
+    for (int p = 0; p < G::NP; ++p) {
+        const int rlo = G::rlo(p), hi = G::hi(p), H = G::H(p);
+        ulonglong2* t = out.data() + start + (size_t)G::table_off(p) * nblk;
+        for (int j = 1; j < G::C; ++j) {
+            int k = 0;
+            while ((2 << k) <= j) ++k;
+            const int o = j - (1 << k), rb_bit = R - 1 - k, b = rlo + rb_bit;
+            if (b > hi) continue;  // stage belongs to an earlier pass (short last pass)
+            const uint32_t m_local = 1u << (L - 1 - b);
+            for (uint32_t blk = 0; blk < nblk; ++blk)
+                for (int h = 0; h < H; ++h) {
+                    const uint32_t idx = (m_local << rb.log_split) + blk * m_local + ((uint32_t)h << k) + (uint32_t)o;
+                    t[(size_t)j * H * nblk + (size_t)blk * H + h] = make_ulonglong2(tw[idx], pre[idx]);
+                }
+        }
+    }
+}
+
+template <int L, int R, int PPB, bool STAGE_OUT>
+hipError_t launch_rb_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    const uint64_t frames_x = fl.batch << pv.rb.log_split;
+    const size_t lds = (size_t)G::lds_elems * 8 * PPB;
+    dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
+    hipLaunchKernelGGL((fwd_regblock<L, R, PPB, STAGE_OUT>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts, pv.tw_rb,
+                       pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
+constexpr bool kStageOut = false;
+
+template <typename F>
+hipError_t set_lds_attr(F* fn, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+unsigned grid_1d(uint64_t work_items, unsigned threads) {
+    uint64_t blocks = (work_items + threads - 1) / threads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048 * 8) blocks = 2048 * 8;  // grid-stride the rest
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+regblock_layout regblock_choose(uint32_t n) {
+    regblock_layout rb;
+    int log_n = 0;
+    while ((1u << log_n) < n) ++log_n;
+    if (log_n < 10) return rb;  // small sizes stay on the radix-2 kernel
+    rb.log_n = log_n;
+    rb.log_split = log_n > kMaxLdsLog ? log_n - kMaxLdsLog : 0;
+    rb.log_local = log_n - rb.log_split;
+    const rb_config* c = rb_find(rb.log_local);
+    if (!c) return regblock_layout{};
+    rb.r = c->r;
+    const uint32_t nblk = 1u << rb.log_split;
+    switch (rb.log_local) {
+        case 10: rb.pairs_per_prime = rb_geom<10, 4>::table_pairs * nblk; break;
+        case 11: rb.pairs_per_prime = rb_geom<11, 4>::table_pairs * nblk; break;
+        case 12: rb.pairs_per_prime = rb_geom<12, 4>::table_pairs * nblk; break;
+        case 13: rb.pairs_per_prime = rb_geom<13, 5>::table_pairs * nblk; break;
+        case 14: rb.pairs_per_prime = rb_geom<14, 5>::table_pairs * nblk; break;
+    }
+    return rb;
+}
+
+void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {
+    switch (rb.log_local) {
+        case 10: build_table_t<10, 4>(rb, tw, pre, out); break;
+        case 11: build_table_t<11, 4>(rb, tw, pre, out); break;
+        case 12: build_table_t<12, 4>(rb, tw, pre, out); break;
+        case 13: build_table_t<13, 5>(rb, tw, pre, out); break;
+        case 14: build_table_t<14, 5>(rb, tw, pre, out); break;
+    }
+}
+
+hipError_t kernels_init() {
+    hipError_t e;
+    const size_t big = (size_t)8 << kMaxLdsLog;
+    if ((e = set_lds_attr(fwd_radix2_lds, big)) != hipSuccess) return e;
+    if ((e = set_lds_attr(inv_radix2_lds, big)) != hipSuccess) return e;
+    if ((e = set_lds_attr(fwd_regblock<10, 4, 4, kStageOut>, (size_t)rb_geom<10, 4>::lds_elems * 8 * 4)) != hipSuccess) return e;
+    if ((e = set_lds_attr(fwd_regblock<11, 4, 2, kStageOut>, (size_t)rb_geom<11, 4>::lds_elems * 8 * 2)) != hipSuccess) return e;
+    if ((e = set_lds_attr(fwd_regblock<12, 4, 1, kStageOut>, (size_t)rb_geom<12, 4>::lds_elems * 8)) != hipSuccess) return e;
+    if ((e = set_lds_attr(fwd_regblock<13, 5, 1, kStageOut>, (size_t)rb_geom<13, 5>::lds_elems * 8)) != hipSuccess) return e;
+    if ((e = set_lds_attr(fwd_regblock<14, 5, 1, kStageOut>, (size_t)rb_geom<14, 5>::lds_elems * 8)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+static unsigned radix2_threads(uint32_t nb) {
+    uint32_t t = nb / 2;
+    if (t < 64) t = 64;
+    if (t > 1024) t = 1024;
+    return t;
+}
+
+hipError_t launch_forward_radix2(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    const uint32_t split = pv.log_n > (uint32_t)kMaxLdsLog ? pv.log_n - kMaxLdsLog : 0;
+    const uint32_t nb_log = pv.log_n - split;
+    const uint64_t* src = in;
+    for (uint32_t st = 0; st < split; ++st) {
+        dim3 grid(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);
+        hipLaunchKernelGGL(fwd_global_stage, grid, dim3(256), 0, s, src, out, pv.consts, pv.tw, pv.log_n, st, fl.batch,
+                           fl.prime_stride, fl.poly_stride);
+        src = out;
+    }
+    dim3 grid((unsigned)(fl.batch << split), pv.num_primes);
+    hipLaunchKernelGGL(fwd_radix2_lds, grid, dim3(radix2_threads(1u << nb_log)), (size_t)8 << nb_log, s, src, out, pv.consts,
+                       pv.tw, pv.log_n, nb_log, split, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_inverse_radix2(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    const uint32_t split = pv.log_n > (uint32_t)kMaxLdsLog ? pv.log_n - kMaxLdsLog : 0;
+    const uint32_t nb_log = pv.log_n - split;
+    dim3 grid((unsigned)(fl.batch << split), pv.num_primes);
+    hipLaunchKernelGGL(inv_radix2_lds, grid, dim3(radix2_threads(1u << nb_log)), (size_t)8 << nb_log, s, in, out, pv.consts,
+                       pv.itw, pv.log_n, nb_log, split, fl.prime_stride, fl.poly_stride);
+    for (int st = (int)split - 1; st >= 0; --st) {
+        dim3 g2(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);
+        hipLaunchKernelGGL(inv_global_stage, g2, dim3(256), 0, s, out, pv.consts, pv.itw, pv.log_n, (uint32_t)st, fl.batch,
+                           fl.prime_stride, fl.poly_stride);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    if (!pv.rb.valid()) return hipErrorInvalidValue;
+    const uint64_t* src = in;
+    for (int st = 0; st < pv.rb.log_split; ++st) {
+        dim3 grid(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);
+        hipLaunchKernelGGL(fwd_global_stage, grid, dim3(256), 0, s, src, out, pv.consts, pv.tw, pv.log_n, (uint32_t)st, fl.batch,
+                           fl.prime_stride, fl.poly_stride);
+        src = out;
+    }
+    switch (pv.rb.log_local) {
+        case 10: return launch_rb_t<10, 4, 4, kStageOut>(pv, src, out, fl, s);
+        case 11: return launch_rb_t<11, 4, 2, kStageOut>(pv, src, out, fl, s);
+        case 12: return launch_rb_t<12, 4, 1, kStageOut>(pv, src, out, fl, s);
+        case 13: return launch_rb_t<13, 5, 1, kStageOut>(pv, src, out, fl, s);
+        case 14: return launch_rb_t<14, 5, 1, kStageOut>(pv, src, out, fl, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_pointwise(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, uint64_t batch, hipStream_t s) {
+    const uint64_t per_prime = batch << pv.log_n;
+    dim3 grid(grid_1d(per_prime, 256), pv.num_primes);
+    hipLaunchKernelGGL(pointwise_kernel, grid, dim3(256), 0, s, a, b, c, pv.consts, per_prime);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(const plan_view& pv, uint64_t* out, uint64_t batch, uint64_t first_poly, uint64_t seed, hipStream_t s) {
+    dim3 grid(grid_1d(batch << pv.log_n, 256), pv.num_primes);
+    hipLaunchKernelGGL(fill_kernel, grid, dim3(256), 0, s, out, pv.consts, pv.log_n, batch, first_poly, seed);
+    return hipGetLastError();
+}
+
+}  // namespace agx

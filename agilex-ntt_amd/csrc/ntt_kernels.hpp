@@ -1,0 +1,56 @@
+// ntt_kernels.hpp -- internal launch interface between the C ABI (agx_ntt.cpp) and the
+// gfx950 kernels (ntt_kernels.hip).  Not installed; the public surface is include/agx_ntt.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <vector>
+
+namespace agx {
+
+struct prime_consts {           // one per prime, device array
+    uint64_t q;
+    uint64_t mu_hi, mu_lo;      // floor(2^128 / q)           (pointwise multiply)
+    uint64_t n_inv, n_inv_p;    // n^-1 mod q and its precomputed quotient      (inverse, last stage)
+    uint64_t w1n, w1n_p;        // inv_twiddle[1] * n^-1 mod q and its quotient  (inverse, last stage)
+    uint64_t pad;
+};
+
+// geometry of one register-blocked configuration (compile-time L, R mirrored at run time)
+struct regblock_layout {
+    int log_n = 0;       // whole transform
+    int log_local = 0;   // sub-transform handled by one workgroup (log_n - log_split)
+    int log_split = 0;   // leading stages done by the global split kernel
+    int r = 0;           // log2 coefficients per thread
+    uint32_t pairs_per_prime = 0;  // table length per prime, in {w,w'} pairs
+    bool valid() const { return r > 0; }
+};
+
+// device-side view of a plan
+struct plan_view {
+    uint32_t n = 0, log_n = 0, num_primes = 0;
+    const prime_consts* consts = nullptr;  // [P]
+    const ulonglong2* tw = nullptr;        // [P][n] {w,w'} natural index   (forward)
+    const ulonglong2* itw = nullptr;       // [P][n] {w,w'} natural index   (inverse) or null
+    regblock_layout rb;                    // forward register-blocked layout
+    const ulonglong2* tw_rb = nullptr;     // [P][rb.pairs_per_prime]
+};
+
+struct frame_layout {
+    uint64_t batch;
+    int64_t prime_stride, poly_stride;  // in elements
+};
+
+// host-side construction of the register-blocked forward table for one prime from its
+// natural-index tables; appends rb.pairs_per_prime pairs to `out`
+regblock_layout regblock_choose(uint32_t n);
+void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out);
+
+hipError_t kernels_init();  // one-time function attributes (large dynamic LDS)
+
+hipError_t launch_forward_radix2(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
+hipError_t launch_inverse_radix2(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
+hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
+hipError_t launch_pointwise(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, uint64_t batch, hipStream_t s);
+hipError_t launch_fill(const plan_view& pv, uint64_t* out, uint64_t batch, uint64_t first_poly, uint64_t seed, hipStream_t s);
+
+}  // namespace agx

@@ -1,0 +1,135 @@
+/*
+ * agx_ntt.h -- C ABI of the MI355X-native batched negacyclic NTT engine.
+ *
+ * This is the drop-in boundary for the forward-NTT path of joekurina/Agilex-NTT
+ * (reference paths are relative to the reference tree).  Everything is plain
+ * pointers and sizes: no SYCL, HIP or torch types appear in a signature
+ * (streams are passed as `void*` holding a hipStream_t; NULL = default stream).
+ *
+ * Data contract (verified against the reference arithmetic):
+ *   one "frame" = one length-n polynomial under one modulus q, n a power of two,
+ *   q prime, q = 1 (mod 2n), q < 2^62, coefficients uint64_t.
+ *   forward : out[bitrev(k)] = sum_j x[j] * psi^((2k+1) j) mod q, fully reduced to [0,q)
+ *             (natural order in, bit-reversed order out; inputs may lie in [0,4q)).
+ *   inverse : exact inverse of forward (bit-reversed in, natural out, [0,q)).
+ *   tables  : twiddle[j] = psi^bitrev(j) mod q,  precon[j] = floor(twiddle[j] * 2^64 / q),
+ *             j = 0..n-1 (index 0 unused by the transform), as the reference expects
+ *             its caller to supply them (include/kernel/ntt.h:35-41).
+ *
+ * Every function returns an agx_status (0 = success) and never throws.
+ */
+#ifndef AGX_NTT_H
+#define AGX_NTT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum agx_status {
+    AGX_OK = 0,
+    AGX_ERR_NULL_POINTER = 1,   /* a required pointer argument is NULL                      */
+    AGX_ERR_BAD_SIZE = 2,       /* n is not a power of two in [AGX_NTT_MIN_N, AGX_NTT_MAX_N] */
+    AGX_ERR_BAD_MODULUS = 3,    /* q >= 2^62, q even, q != 1 (mod 2n) or (plan_create_auto) q composite */
+    AGX_ERR_BAD_ROOT = 4,       /* psi is not a primitive 2n-th root of unity mod q           */
+    AGX_ERR_BAD_ARGUMENT = 5,   /* zero primes, negative stride, overlapping in/out, ...      */
+    AGX_ERR_NO_DEVICE = 6,      /* no usable HIP device                                       */
+    AGX_ERR_HIP = 7,            /* a HIP runtime call failed (agx_ntt_last_hip_error)         */
+    AGX_ERR_ALLOC = 8,          /* host or device allocation failed                           */
+    AGX_ERR_NO_INVERSE = 9      /* plan was created without inverse tables                    */
+} agx_status;
+
+#define AGX_NTT_MIN_N 2u
+#define AGX_NTT_MAX_N 32768u  /* the reference's largest size (include/kernel/ntt.h:19-20) */
+
+/* kernel variants (agx_ntt_plan_set_variant); AUTO picks the tuned kernel for n */
+#define AGX_VARIANT_AUTO 0
+#define AGX_VARIANT_LDS_RADIX2 1 /* one stage per barrier, LDS resident: mirrors the reference's op sequence */
+#define AGX_VARIANT_REGBLOCK 2   /* register-blocked radix-2^R passes */
+
+const char* agx_ntt_strerror(int status);
+int agx_ntt_last_hip_error(void);     /* hipError_t of the last AGX_ERR_HIP on this thread */
+int agx_ntt_device_count(int* count); /* AGX_OK and *count = 0 when there is no GPU */
+
+/* ------------------------------------------------------------------------- */
+/* (1) One-shot host-pointer forward NTT.                                     */
+/* Replaces the reference's three calls taken together:                        */
+/*   ntt_input_kernel(inData, inData2, modulus, twiddleFactors,                */
+/*                    barrettTwiddleFactors, numFrames, q)  include/kernel/ntt.h:35-41 */
+/*   fwd_ntt_kernel<0>(q)                                   include/kernel/ntt.h:32-33 */
+/*   ntt_output_kernel(outData, numFrames, q)               include/kernel/ntt.h:43-45 */
+/* Reads only in[b*n + 0 .. n/2) and in2[b*n + n/2 .. n) (src/kernel/ntt.cpp:584-590; */
+/* in2 may alias in), writes out[b*n + p] (src/kernel/ntt.cpp:628-633).  n is a */
+/* runtime argument here (the reference fixes it at compile time,              */
+/* include/kernel/ntt.h:7-23).  Synchronous; all pointers are host memory.     */
+/* ------------------------------------------------------------------------- */
+int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
+                         const uint64_t* twiddles, const uint64_t* precons, uint64_t* out,
+                         uint32_t n, uint32_t num_frames);
+
+/* ------------------------------------------------------------------------- */
+/* (2) Plans: device-resident tables for num_primes moduli of one size n.      */
+/* A plan is immutable after creation and may be shared between host threads;  */
+/* it belongs to the HIP device that was current when it was created.          */
+/* ------------------------------------------------------------------------- */
+typedef struct agx_ntt_plan agx_ntt_plan;
+
+/* caller-supplied tables, laid out [num_primes][n] (one reference launch per prime,
+ * src/kernel/ntt.cpp:143-144,569).  inv_* may both be NULL (forward-only plan).
+ * n_inv[p] = n^-1 mod q_p is derived internally. */
+int agx_ntt_plan_create(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, const uint64_t* moduli,
+                        const uint64_t* twiddles, const uint64_t* precons,
+                        const uint64_t* inv_twiddles, const uint64_t* inv_precons);
+
+/* tables generated by the library; psi == NULL -> smallest primitive 2n-th root per prime */
+int agx_ntt_plan_create_auto(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes,
+                             const uint64_t* moduli, const uint64_t* psi);
+int agx_ntt_plan_destroy(agx_ntt_plan* plan);
+int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant); /* testing / benchmarking only */
+int agx_ntt_plan_info(const agx_ntt_plan* plan, uint32_t* n, uint32_t* num_primes, int* device, int* has_inverse);
+int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uint64_t* q, uint64_t* psi);
+
+/* ------------------------------------------------------------------------- */
+/* (3) Device-pointer batched transforms.  Frame (p, b) starts at              */
+/* base + p*prime_stride + b*poly_stride (strides in uint64_t elements);       */
+/* the dense forms use the [prime][batch][n] layout (prime_stride = batch*n,   */
+/* poly_stride = n).  In place (d_out == d_in) is allowed.  Asynchronous on    */
+/* `stream`; nothing is allocated or synchronised inside, so the calls can be  */
+/* captured into a hipGraph.                                                    */
+/* ------------------------------------------------------------------------- */
+int agx_ntt_forward(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
+int agx_ntt_inverse(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
+int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
+                            int64_t prime_stride, int64_t poly_stride, void* stream);
+int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
+                            int64_t prime_stride, int64_t poly_stride, void* stream);
+
+/* c = a o b (coefficient-wise product mod q_p), dense [prime][batch][n] layout; c may alias a or b */
+int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
+                      uint64_t batch, void* stream);
+/* c = a * b in Z_q[X]/(X^n + 1) = INTT(NTT(a) o NTT(b)); dense layout; c may alias a or b.
+ * d_scratch: num_primes*batch*n elements of device memory owned by the caller, distinct from a, b, c. */
+int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
+                    uint64_t* d_scratch, uint64_t batch, void* stream);
+
+/* synthetic coefficients generated on the device: frame (p,b) element i =
+ * splitmix64(seed, p, first_poly + b, i) mod q_p, a pure function of its indices (bench / tests) */
+int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t batch, uint64_t first_poly,
+                           uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* (4) Host math the reference leaves to its caller (src/main.cpp:49-55 ships   */
+/* placeholders only).                                                          */
+/* ------------------------------------------------------------------------- */
+/* the `count` largest primes q < 2^bits with q = 1 (mod 2n), descending */
+int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t* primes_out);
+int agx_ntt_min_root(uint64_t q, uint32_t n, uint64_t* psi_out);
+int agx_ntt_make_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* twiddles, uint64_t* precons);
+int agx_ntt_make_inverse_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* inv_twiddles, uint64_t* inv_precons);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGX_NTT_H */

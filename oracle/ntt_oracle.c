@@ -1,0 +1,325 @@
+/*
+ * oracle/ntt_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the forward negacyclic NTT arithmetic of
+ * joekurina/Agilex-NTT (src/kernel/ntt.cpp), plus the mathematically defined
+ * inverse / pointwise steps the reference does not ship.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object; the product library (agilex-ntt_amd/lib/libagxntt.so) never
+ * links, loads or calls it.
+ *
+ * Parity status
+ *   forward NTT : restates ntt.cpp:147-180 (stage / index structure),
+ *                 :298-300 (twiddle index m+i), :331-332 (lazy reduce of X),
+ *                 :344-363 (precomputed-quotient multiply), :368-369 (outputs),
+ *                 :377-394 (final reduction), :584-590 and :628-633 (I/O layout).
+ *                 The reference needs the oneAPI SYCL headers (CL/sycl.hpp,
+ *                 sycl/ext/intel/fpga_extensions.hpp), which this image lacks, so
+ *                 it is unbuildable here and there is no oracle/_ref.  The
+ *                 reference ships no golden vectors either.  The restatement is
+ *                 pinned by (i) the checksum anchors SURVEY.md section 8c recorded
+ *                 from the reference's own butterfly code (tests/golden/
+ *                 survey_anchors.json) and (ii) an independent O(n^2) evaluation
+ *                 of the closed-form contract (oracle_naive_forward below).
+ *   inverse NTT, pointwise multiply, polymul: "parity unpinned" -- the reference
+ *                 has no such code; pinned by mathematics only
+ *                 (round trip, naive inverse, schoolbook negacyclic product).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------ */
+/* scalar modular helpers (oracle only)                                */
+/* ------------------------------------------------------------------ */
+static uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) {
+    return (uint64_t)(((u128)a * b) % q);
+}
+
+static uint64_t powmod(uint64_t a, uint64_t e, uint64_t q) {
+    uint64_t r = 1 % q;
+    a %= q;
+    while (e) {
+        if (e & 1) r = mulmod(r, a, q);
+        a = mulmod(a, a, q);
+        e >>= 1;
+    }
+    return r;
+}
+
+uint64_t oracle_mulmod(uint64_t a, uint64_t b, uint64_t q) { return mulmod(a, b, q); }
+uint64_t oracle_powmod(uint64_t a, uint64_t e, uint64_t q) { return powmod(a, e, q); }
+uint64_t oracle_invmod(uint64_t a, uint64_t q) { return powmod(a, q - 2, q); }
+
+static uint32_t bitrev(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+uint32_t oracle_bitrev(uint32_t x, int bits) { return bitrev(x, bits); }
+
+static int ilog2(uint32_t n) { int l = 0; while ((1u << l) < n) l++; return l; }
+
+/* deterministic Miller-Rabin for 64-bit inputs */
+int oracle_is_prime(uint64_t n) {
+    static const uint64_t bases[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    if (n < 2) return 0;
+    for (size_t i = 0; i < sizeof(bases) / sizeof(bases[0]); i++) {
+        if (n % bases[i] == 0) return n == bases[i];
+    }
+    uint64_t d = n - 1; int s = 0;
+    while (!(d & 1)) { d >>= 1; s++; }
+    for (size_t i = 0; i < sizeof(bases) / sizeof(bases[0]); i++) {
+        uint64_t x = powmod(bases[i], d, n);
+        if (x == 1 || x == n - 1) continue;
+        int comp = 1;
+        for (int r = 1; r < s; r++) {
+            x = mulmod(x, x, n);
+            if (x == n - 1) { comp = 0; break; }
+        }
+        if (comp) return 0;
+    }
+    return 1;
+}
+
+/* k-th (k = 0,1,..) largest prime below 2^bits with q = 1 (mod 2n)  (SURVEY 8c recipe) */
+uint64_t oracle_find_prime(int bits, uint32_t n, int k) {
+    uint64_t step = 2ull * n;
+    uint64_t top = (bits >= 64) ? ~0ull : ((1ull << bits) - 1);
+    uint64_t q = top - ((top - 1) % step); /* largest value <= top that is 1 mod 2n */
+    for (; q > step; q -= step) {
+        if (oracle_is_prime(q)) { if (k-- == 0) return q; }
+    }
+    return 0;
+}
+
+/* smallest primitive 2n-th root of unity mod q (SURVEY 8c recipe); 0 if none */
+uint64_t oracle_min_root(uint64_t q, uint32_t n) {
+    uint64_t order = 2ull * n;
+    if ((q - 1) % order) return 0;
+    uint64_t cof = (q - 1) / order, root = 0;
+    for (uint64_t g = 2; g < q; g++) {
+        uint64_t r = powmod(g, cof, q);
+        if (powmod(r, n, q) == q - 1) { root = r; break; }
+    }
+    if (!root) return 0;
+    /* all primitive roots are the odd powers of `root`; take the least */
+    uint64_t r2 = mulmod(root, root, q), cur = root, best = root;
+    for (uint32_t i = 0; i < n; i++) {
+        if (cur < best) best = cur;
+        cur = mulmod(cur, r2, q);
+    }
+    return best;
+}
+
+/* tables the reference expects its caller to supply (ntt.h:35-41):
+ *   twiddle[j] = psi^bitrev_logn(j) mod q ;  precon[j] = floor(twiddle[j] * 2^64 / q) */
+void oracle_make_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t *tw, uint64_t *pre) {
+    int lg = ilog2(n);
+    uint64_t *pw = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    pw[0] = 1;
+    for (uint32_t i = 1; i < n; i++) pw[i] = mulmod(pw[i - 1], psi, q);
+    for (uint32_t j = 0; j < n; j++) {
+        tw[j] = pw[bitrev(j, lg)];
+        pre[j] = (uint64_t)((((u128)tw[j]) << 64) / q);
+    }
+    free(pw);
+}
+
+/* inverse tables for the Gentleman-Sande pass: itw[j] = twiddle[j]^-1 mod q */
+void oracle_make_inv_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t *itw, uint64_t *ipre) {
+    int lg = ilog2(n);
+    uint64_t ipsi = powmod(psi, q - 2, q);
+    uint64_t *pw = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    pw[0] = 1;
+    for (uint32_t i = 1; i < n; i++) pw[i] = mulmod(pw[i - 1], ipsi, q);
+    for (uint32_t j = 0; j < n; j++) {
+        itw[j] = pw[bitrev(j, lg)];
+        ipre[j] = (uint64_t)((((u128)itw[j]) << 64) / q);
+    }
+    free(pw);
+}
+
+/* ------------------------------------------------------------------ */
+/* forward NTT: restatement of the reference butterfly                 */
+/* ------------------------------------------------------------------ */
+
+/* high 64 bits of a*b by 32-bit halves, as the reference spells it out
+ * (ntt.cpp:344-362, macros :26-30).  Exact, so equal to (u128)a*b >> 64. */
+static inline uint64_t mulhi_split(uint64_t a, uint64_t b) {
+    uint64_t al = (uint32_t)a, ah = a >> 32, bl = (uint32_t)b, bh = b >> 32;
+    uint64_t ll = al * bl, lh = al * bh, hl = ah * bl, hh = ah * bh;
+    uint64_t mid = (ll >> 32) + (uint32_t)hl + (uint32_t)lh;
+    return hh + (hl >> 32) + (lh >> 32) + (mid >> 32);
+}
+
+/* one frame, in place on a[n]; a[] holds values in [0,4q) on entry */
+static void fwd_frame(uint64_t *a, uint32_t n, uint64_t q, const uint64_t *tw, const uint64_t *pre) {
+    const uint64_t q2 = q << 1;
+    uint32_t t = n >> 1;
+    for (uint32_t m = 1; m < n; m <<= 1, t >>= 1) {          /* ntt.cpp:155 */
+        const int last = (m == (n >> 1));
+        for (uint32_t i = 0; i < m; i++) {                   /* group index */
+            const uint64_t W = tw[m + i], Wp = pre[m + i];    /* ntt.cpp:298-300 */
+            uint64_t *x = a + (size_t)2 * i * t, *y = x + t;
+            for (uint32_t j = 0; j < t; j++) {
+                uint64_t tx = x[j];
+                if (tx >= q2) tx -= q2;                       /* ntt.cpp:331-332 */
+                uint64_t Y = y[j];
+                uint64_t c = mulhi_split(Y, Wp);              /* ntt.cpp:344-362 */
+                uint64_t Q = W * Y - c * q;                   /* ntt.cpp:363, mod 2^64 */
+                uint64_t r0 = tx + Q;                         /* ntt.cpp:368 */
+                uint64_t r1 = tx + q2 - Q;                    /* ntt.cpp:369 */
+                if (last) {                                   /* ntt.cpp:377-394 */
+                    if (r0 >= q2) r0 -= q2;
+                    if (r0 >= q) r0 -= q;
+                    if (r1 >= q2) r1 -= q2;
+                    if (r1 >= q) r1 -= q;
+                }
+                x[j] = r0;
+                y[j] = r1;
+            }
+        }
+    }
+}
+
+/* Whole reference path for num_frames frames with one modulus:
+ * lower half of each frame from in, upper half from in2 (ntt.cpp:584-590),
+ * outputs at out[b*n + p] (ntt.cpp:628-633). */
+void oracle_forward(const uint64_t *in, const uint64_t *in2, uint64_t q,
+                    const uint64_t *tw, const uint64_t *pre,
+                    uint64_t *out, uint32_t n, uint64_t num_frames) {
+    for (uint64_t b = 0; b < num_frames; b++) {
+        uint64_t *a = out + b * n;
+        if (n == 1) { a[0] = in[b]; continue; }
+        memmove(a, in + b * n, sizeof(uint64_t) * (n / 2));
+        memmove(a + n / 2, in2 + b * n + n / 2, sizeof(uint64_t) * (n / 2));
+        fwd_frame(a, n, q, tw, pre);
+    }
+}
+
+/* independent second opinion: closed-form contract, O(n^2)
+ *   out[bitrev(k)] = sum_j x[j] * psi^((2k+1) j) mod q           */
+void oracle_naive_forward(const uint64_t *x, uint64_t q, uint64_t psi, uint64_t *out, uint32_t n) {
+    int lg = ilog2(n);
+    uint64_t *pw = (uint64_t *)malloc(sizeof(uint64_t) * 2 * n);
+    pw[0] = 1;
+    for (uint32_t i = 1; i < 2 * n; i++) pw[i] = mulmod(pw[i - 1], psi, q);
+    for (uint32_t k = 0; k < n; k++) {
+        uint64_t acc = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            uint64_t e = ((uint64_t)(2 * k + 1) * j) % (2ull * n);
+            acc = (uint64_t)(((u128)acc + (u128)mulmod(x[j] % q, pw[e], q)) % q);
+        }
+        out[bitrev(k, lg)] = acc;
+    }
+    free(pw);
+}
+
+/* ------------------------------------------------------------------ */
+/* inverse / pointwise / polymul: no reference code (parity unpinned)  */
+/* ------------------------------------------------------------------ */
+
+/* Gentleman-Sande inverse of fwd_frame: bit-reversed in, natural out, [0,q).
+ * Written with plain u128 arithmetic on purpose -- it defines the answer, it
+ * does not mimic any kernel. */
+static void inv_frame(uint64_t *a, uint32_t n, uint64_t q, const uint64_t *itw) {
+    uint32_t t = 1;
+    for (uint32_t m = n >> 1; m >= 1; m >>= 1, t <<= 1) {
+        for (uint32_t i = 0; i < m; i++) {
+            const uint64_t W = itw[m + i];
+            uint64_t *x = a + (size_t)2 * i * t, *y = x + t;
+            for (uint32_t j = 0; j < t; j++) {
+                uint64_t u = x[j] % q, v = y[j] % q;
+                uint64_t s = u + v; if (s >= q) s -= q;
+                uint64_t d = u >= v ? u - v : u + q - v;
+                x[j] = s;
+                y[j] = mulmod(d, W, q);
+            }
+        }
+    }
+    uint64_t ninv = powmod(n % q, q - 2, q);
+    for (uint32_t j = 0; j < n; j++) a[j] = mulmod(a[j], ninv, q);
+}
+
+void oracle_inverse(const uint64_t *in, uint64_t q, const uint64_t *itw,
+                    uint64_t *out, uint32_t n, uint64_t num_frames) {
+    for (uint64_t b = 0; b < num_frames; b++) {
+        uint64_t *a = out + b * n;
+        memmove(a, in + b * n, sizeof(uint64_t) * n);
+        if (n > 1) inv_frame(a, n, q, itw);
+    }
+}
+
+void oracle_pointwise(const uint64_t *a, const uint64_t *b, uint64_t q, uint64_t *c, uint64_t count) {
+    for (uint64_t i = 0; i < count; i++) c[i] = mulmod(a[i] % q, b[i] % q, q);
+}
+
+/* schoolbook product in Z_q[X]/(X^n+1) */
+void oracle_negacyclic_schoolbook(const uint64_t *a, const uint64_t *b, uint64_t q, uint64_t *c, uint32_t n) {
+    for (uint32_t k = 0; k < n; k++) c[k] = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t ai = a[i] % q;
+        for (uint32_t j = 0; j < n; j++) {
+            uint64_t p = mulmod(ai, b[j] % q, q);
+            uint32_t k = i + j;
+            if (k < n) { c[k] += p; if (c[k] >= q) c[k] -= q; }
+            else { k -= n; c[k] = c[k] >= p ? c[k] - p : c[k] + q - p; }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* input recipe + checksum of SURVEY 8c (anchors)                      */
+/* ------------------------------------------------------------------ */
+static uint64_t splitmix_next(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void oracle_fill_splitmix(uint64_t *x, uint64_t count, uint64_t seed, uint64_t q) {
+    uint64_t s = seed;
+    for (uint64_t i = 0; i < count; i++) x[i] = splitmix_next(&s) % q;
+}
+
+uint64_t oracle_fnv1a_words(const uint64_t *x, uint64_t count) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint64_t i = 0; i < count; i++) { h ^= x[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+/* ------------------------------------------------------------------ */
+/* timed CPU baseline: the forward restatement over a batch, threaded  */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    const uint64_t *in; uint64_t *out; uint64_t q;
+    const uint64_t *tw, *pre; uint32_t n; uint64_t b0, b1;
+} fwd_job;
+
+static void *fwd_worker(void *p) {
+    fwd_job *j = (fwd_job *)p;
+    if (j->b1 > j->b0)
+        oracle_forward(j->in + j->b0 * j->n, j->in + j->b0 * j->n, j->q, j->tw, j->pre,
+                       j->out + j->b0 * j->n, j->n, j->b1 - j->b0);
+    return 0;
+}
+
+/* frames split into contiguous blocks over `threads` pthreads */
+int oracle_forward_mt(const uint64_t *in, uint64_t q, const uint64_t *tw, const uint64_t *pre,
+                      uint64_t *out, uint32_t n, uint64_t num_frames, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t tid[256]; fwd_job job[256];
+    for (int t = 0; t < threads; t++) {
+        job[t] = (fwd_job){in, out, q, tw, pre, n,
+                           num_frames * (uint64_t)t / threads, num_frames * (uint64_t)(t + 1) / threads};
+        if (pthread_create(&tid[t], 0, fwd_worker, &job[t])) return -1;
+    }
+    for (int t = 0; t < threads; t++) pthread_join(tid[t], 0);
+    return 0;
+}

@@ -1,0 +1,115 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/agx_ntt.h declares, validates arguments, and its host math agrees with the oracle.
+No compute call can succeed here (no GPU): the product path must fail loudly, not fall back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "agx_ntt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(agx_ntt_\w+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(agx):
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    assert sorted(agx.ABI) == declared
+
+
+def test_library_exports_every_declared_symbol(agx):
+    raw = ctypes.CDLL(agx.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(raw, name), name
+
+
+def test_no_torch_or_oracle_in_product_library(agx):
+    """the shipped library links neither torch nor the oracle"""
+    import subprocess
+
+    needed = subprocess.run(["readelf", "-d", agx.LIB_PATH], capture_output=True, text=True).stdout
+    assert "torch" not in needed and "oracle" not in needed
+    assert "amdhip64" in needed
+
+
+def test_strerror(agx):
+    L = agx.lib()
+    assert L.agx_ntt_strerror(0) == b"success"
+    for code in range(1, 10):
+        assert L.agx_ntt_strerror(code) not in (b"", b"unknown status")
+    assert L.agx_ntt_strerror(1234) == b"unknown status"
+
+
+@pytest.mark.parametrize("n,bits", [(32, 30), (1024, 30), (4096, 60), (8192, 61), (16384, 60), (32768, 60)])
+def test_host_math_matches_oracle(agx, orc, n, bits):
+    qs = agx.find_primes(bits, n, 3)
+    assert qs == [orc.find_prime(bits, n, k) for k in range(3)]
+    q = qs[0]
+    psi = agx.min_root(q, n)
+    assert psi == orc.min_root(q, n)
+    tw, pre = agx.make_tables(q, psi, n)
+    otw, opre = orc.make_tables(q, psi, n)
+    assert np.array_equal(tw, otw) and np.array_equal(pre, opre)
+    itw, ipre = agx.make_tables(q, psi, n, inverse=True)
+    oitw, oipre = orc.make_inv_tables(q, psi, n)
+    assert np.array_equal(itw, oitw) and np.array_equal(ipre, oipre)
+
+
+def test_argument_validation(agx):
+    L = agx.lib()
+    out = np.zeros(4, dtype=np.uint64)
+    p64 = ctypes.POINTER(ctypes.c_uint64)
+    ptr = out.ctypes.data_as(p64)
+    assert L.agx_ntt_find_primes(60, 4096, 1, None) == 1          # NULL
+    assert L.agx_ntt_find_primes(60, 1000, 1, ptr) == 2           # not a power of two
+    assert L.agx_ntt_find_primes(60, 65536, 1, ptr) == 2          # beyond AGX_NTT_MAX_N
+    assert L.agx_ntt_find_primes(63, 4096, 1, ptr) == 5           # q must stay below 2^62
+    r = ctypes.c_uint64(0)
+    assert L.agx_ntt_min_root(65537, 16384, ctypes.byref(r)) == 0  # the reference's example modulus (main.cpp:55)
+    assert L.agx_ntt_min_root(65536, 16, ctypes.byref(r)) == 3     # even
+    assert L.agx_ntt_min_root(97, 64, ctypes.byref(r)) == 3        # 96 not divisible by 128
+    assert L.agx_ntt_min_root((1 << 62) + 1, 2, ctypes.byref(r)) == 3  # too large
+    assert L.agx_ntt_make_tables(97, 5, 16, ptr, ptr) == 4         # 5 is not a primitive 32nd root mod 97
+    h = ctypes.c_void_p(None)
+    mods = np.array([97], dtype=np.uint64)
+    mp = mods.ctypes.data_as(p64)
+    assert L.agx_ntt_plan_create_auto(ctypes.byref(h), 24, 1, mp, None) == 2
+    assert L.agx_ntt_plan_create_auto(ctypes.byref(h), 16, 0, mp, None) == 5
+    assert L.agx_ntt_plan_create_auto(None, 16, 1, mp, None) == 1
+    mods[0] = 33  # 1 mod 32 but composite
+    assert L.agx_ntt_plan_create_auto(ctypes.byref(h), 16, 1, mp, None) == 3
+    assert L.agx_ntt_forward(None, None, None, 1, None) == 1
+    assert L.agx_ntt_plan_destroy(None) == 0
+
+
+def test_product_fails_loudly_without_gpu(agx):
+    """there is no CPU fallback behind the boundary: without a device every compute entry
+    point reports AGX_ERR_NO_DEVICE"""
+    if agx.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(agx.AgxError) as ei:
+        agx.Plan(16, [97])
+    assert ei.value.status == 6
+    q = agx.find_primes(30, 32)[0]
+    tw, pre = agx.make_tables(q, agx.min_root(q, 32), 32)
+    x = np.zeros(32, dtype=np.uint64)
+    with pytest.raises(agx.AgxError) as ei:
+        agx.forward_host(x, x, q, tw, pre, 32, 1)
+    assert ei.value.status == 6
+
+
+def test_product_sources_never_reference_the_oracle():
+    pkg = os.path.join(ROOT, "agilex-ntt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if any(part in ("build", "lib", "bin", "__pycache__") for part in dirpath.split(os.sep)):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)

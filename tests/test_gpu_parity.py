@@ -1,0 +1,350 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+must be bit-exact against the CPU oracle on the same inputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import rand_coeffs, tables_for
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL_SIZES = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768]
+
+
+def _plan_from_oracle_tables(agx, orc, n, bits, count, inverse=True):
+    tabs = tables_for(orc, n, bits, count)
+    tw = np.stack([t[2] for t in tabs])
+    pre = np.stack([t[3] for t in tabs])
+    tables = [tw, pre]
+    if inverse:
+        inv = [orc.make_inv_tables(t[0], t[1], n) for t in tabs]
+        tables += [np.stack([i[0] for i in inv]), np.stack([i[1] for i in inv])]
+    return agx.Plan(n, [t[0] for t in tabs], tables=tuple(tables)), tabs
+
+
+def _oracle_forward_rns(orc, x, tabs, n, batch):
+    """x: [P][batch][n] flat"""
+    out = np.empty_like(x)
+    for p, (q, _, tw, pre) in enumerate(tabs):
+        sl = slice(p * batch * n, (p + 1) * batch * n)
+        out[sl] = orc.forward(x[sl], q, tw, pre, n)
+    return out
+
+
+@pytest.mark.parametrize("variant", ["radix2", "regblock"])
+@pytest.mark.parametrize("n", ALL_SIZES)
+def test_forward_bit_exact(agx, orc, dev, n, variant):
+    if variant == "regblock" and n < 1024:
+        pytest.skip("register-blocked kernels start at n=1024")
+    bits = 30 if n == 1024 else (61 if n in (8, 8192) else 60)
+    batch = 5 if n <= 4096 else 3          # ragged: not a multiple of polys-per-block
+    primes = 2 if n <= 8192 else 1
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
+    plan.set_variant(agx.VARIANT_LDS_RADIX2 if variant == "radix2" else agx.VARIANT_REGBLOCK)
+    rng = np.random.default_rng(n * 3 + primes)
+    x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])  # lazy range [0,4q)
+    d_in = dev.to_device(x)
+    d_out = dev.empty(x.size)
+    plan.forward(d_in.data_ptr(), d_out.data_ptr(), batch, dev.stream)
+    got = dev.to_host(d_out)
+    want = _oracle_forward_rns(orc, x, tabs, n, batch)
+    assert np.array_equal(got, want)
+    assert np.array_equal(dev.to_host(d_in), x), "input must not be modified"
+    # in place
+    plan.forward(d_in.data_ptr(), d_in.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_in), want)
+    plan.close()
+
+
+def test_golden_vectors_on_gpu(agx, orc, dev):
+    with open(os.path.join(GOLDEN, "forward_vectors.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        n, q, psi = c["n"], int(c["q"]), int(c["psi"])
+        plan = agx.Plan(n, [q], psi=[psi])
+        assert plan.psi(0) == psi
+        x = orc.fill_splitmix(n * c["frames"], c["seed"], q)
+        d = dev.to_device(x)
+        plan.forward(d.data_ptr(), d.data_ptr(), c["frames"], dev.stream)
+        y = dev.to_host(d)
+        assert "%016x" % orc.fnv1a_words(y) == c["fnv1a_words"], c["n"]
+        assert [int(v) for v in y[:8]] == [int(v) for v in c["first8"]]
+        assert [int(v) for v in y[-8:]] == [int(v) for v in c["last8"]]
+        if "output" in c:
+            assert [int(v) for v in y] == [int(v) for v in c["output"]]
+        plan.close()
+
+
+def test_survey_anchor_words_on_gpu(agx, orc, dev):
+    """the output words SURVEY.md 8c recorded from the reference's own kernel code"""
+    with open(os.path.join(GOLDEN, "survey_anchors.json")) as f:
+        anchors = json.load(f)["anchors"]
+    for a in anchors:
+        if not a["out_first"]:
+            continue
+        n, q = a["n"], int(a["q"])
+        plan = agx.Plan(n, [q])  # library picks the least root itself
+        assert plan.psi(0) == int(a["psi"])
+        x = orc.fill_splitmix(n * a["frames"], 42, q)
+        d = dev.to_device(x)
+        plan.forward(d.data_ptr(), d.data_ptr(), a["frames"], dev.stream)
+        y = dev.to_host(d)
+        assert [int(v) for v in y[:len(a["out_first"])]] == [int(v) for v in a["out_first"]]
+        plan.close()
+
+
+@pytest.mark.parametrize("n,bits,frames", [(32, 30, 2), (1024, 30, 1), (1024, 30, 7), (4096, 60, 3), (16384, 60, 2), (32768, 60, 1)])
+def test_one_shot_host_call(agx, orc, n, bits, frames):
+    """agx_ntt_forward_host = ntt_input_kernel + fwd_ntt_kernel<0> + ntt_output_kernel;
+    lower half of each frame from `in`, upper half from `in2` (ntt.cpp:584-590)"""
+    (q, psi, tw, pre), = tables_for(orc, n, bits)
+    rng = np.random.default_rng(n + frames)
+    a = rand_coeffs(rng, frames * n, q)
+    b = rand_coeffs(rng, frames * n, q)
+    got = agx.forward_host(a, b, q, tw, pre, n, frames)
+    assert np.array_equal(got, orc.forward(a, q, tw, pre, n, x2=b))
+    got_same = agx.forward_host(a, a, q, tw, pre, n, frames)
+    assert np.array_equal(got_same, orc.forward(a, q, tw, pre, n))
+
+
+def test_reference_smoke_inputs_are_reproduced(agx, orc):
+    """main.cpp:49-55 feeds placeholder tables that break the precon contract; the reference
+    then computes 64-bit wrap-around garbage.  Same operation sequence here, so the
+    garbage matches the oracle bit for bit as well."""
+    n = 16384
+    i = np.arange(n, dtype=np.uint64)
+    got = agx.forward_host(i, i + np.uint64(1), 65537, i + np.uint64(2), i + np.uint64(3), n, 1)
+    want = orc.forward(i, 65537, i + np.uint64(2), i + np.uint64(3), n, x2=i + np.uint64(1))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [32, 1024, 4096])
+def test_structured_known_answers(agx, dev, n):
+    q = agx.find_primes(30 if n == 1024 else 60, n)[0]
+    plan = agx.Plan(n, [q])
+    psi = plan.psi(0)
+    lg = n.bit_length() - 1
+    x = np.zeros(4 * n, dtype=np.uint64)
+    x[n] = 1                 # frame 1: delta_0
+    x[2 * n + 1] = 1         # frame 2: X
+    x[3 * n:] = q - 1        # frame 3: all q-1
+    d = dev.to_device(x)
+    plan.forward(d.data_ptr(), d.data_ptr(), 4, dev.stream)
+    y = dev.to_host(d).reshape(4, n)
+    assert not y[0].any()
+    assert (y[1] == 1).all()
+    for k in range(n):
+        assert int(y[2][int("{:0{w}b}".format(k, w=lg)[::-1], 2)]) == pow(psi, 2 * k + 1, q)
+    assert (y[3] < q).all()
+    plan.close()
+
+
+@pytest.mark.parametrize("n", ALL_SIZES)
+def test_inverse_round_trip_and_oracle(agx, orc, dev, n):
+    bits = 30 if n == 1024 else 60
+    batch, primes = 3, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
+    rng = np.random.default_rng(n + 11)
+    x = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+    d_x = dev.to_device(x)
+    d_y = dev.empty(x.size)
+    plan.forward(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+    y = dev.to_host(d_y)
+    d_z = dev.empty(x.size)
+    plan.inverse(d_y.data_ptr(), d_z.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_z), x)
+    # against the oracle's inverse on arbitrary (not forward-image) data
+    r = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+    d_r = dev.to_device(r)
+    plan.inverse(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
+    want = np.concatenate([orc.inverse(r[p * batch * n:(p + 1) * batch * n], tabs[p][0],
+                                       orc.make_inv_tables(tabs[p][0], tabs[p][1], n)[0], n) for p in range(primes)])
+    assert np.array_equal(dev.to_host(d_r), want)
+    assert np.array_equal(y, _oracle_forward_rns(orc, x, tabs, n, batch))
+    plan.close()
+
+
+@pytest.mark.parametrize("n,bits", [(64, 30), (1024, 60), (4096, 61)])
+def test_pointwise_and_polymul(agx, orc, dev, n, bits):
+    batch, primes = 3, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
+    rng = np.random.default_rng(n + 5)
+    a = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+    b = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+    d_a, d_b, d_c, d_s = dev.to_device(a), dev.to_device(b), dev.empty(a.size), dev.empty(a.size)
+    plan.pointwise(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), batch, dev.stream)
+    want = np.concatenate([orc.pointwise(a[p * batch * n:(p + 1) * batch * n], b[p * batch * n:(p + 1) * batch * n], tabs[p][0])
+                           for p in range(primes)])
+    assert np.array_equal(dev.to_host(d_c), want)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), batch, dev.stream)
+    c = dev.to_host(d_c)
+    for p in range(primes):
+        for f in range(batch):
+            sl = slice((p * batch + f) * n, (p * batch + f + 1) * n)
+            assert np.array_equal(c[sl], orc.schoolbook(a[sl], b[sl], tabs[p][0], n))
+    # c aliasing a
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_a.data_ptr(), d_s.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_a), c)
+    plan.close()
+
+
+def test_strided_poly_major_layout(agx, orc, dev):
+    """[poly][prime][n] callers: prime_stride = n, poly_stride = P*n"""
+    n, batch, primes = 4096, 4, 3
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
+    rng = np.random.default_rng(77)
+    x = np.empty((batch, primes, n), dtype=np.uint64)
+    for p in range(primes):
+        x[:, p, :] = rand_coeffs(rng, batch * n, tabs[p][0]).reshape(batch, n)
+    d = dev.to_device(x.reshape(-1))
+    plan.forward_strided(d.data_ptr(), d.data_ptr(), batch, n, primes * n, dev.stream)
+    y = dev.to_host(d).reshape(batch, primes, n)
+    for p, (q, _, tw, pre) in enumerate(tabs):
+        assert np.array_equal(y[:, p, :].reshape(-1), orc.forward(np.ascontiguousarray(x[:, p, :]).reshape(-1), q, tw, pre, n))
+    plan.inverse_strided(d.data_ptr(), d.data_ptr(), batch, n, primes * n, dev.stream)
+    assert np.array_equal(dev.to_host(d).reshape(batch, primes, n), x)
+    plan.close()
+
+
+def test_empty_batch_and_errors(agx, dev):
+    q = agx.find_primes(60, 4096)[0]
+    plan = agx.Plan(4096, [q])
+    d = dev.empty(4096)
+    plan.forward(d.data_ptr(), d.data_ptr(), 0, dev.stream)  # no-op, no launch
+    with pytest.raises(agx.AgxError) as ei:
+        plan.forward(0, d.data_ptr(), 1, dev.stream)
+    assert ei.value.status == 1
+    tw, pre = agx.make_tables(q, plan.psi(0), 4096)
+    fwd_only = agx.Plan(4096, [q], tables=(tw[None, :], pre[None, :]))
+    with pytest.raises(agx.AgxError) as ei:
+        fwd_only.inverse(d.data_ptr(), d.data_ptr(), 1, dev.stream)
+    assert ei.value.status == 9
+    plan.close()
+    fwd_only.close()
+
+
+def test_fill_synthetic_is_shard_invariant(agx, dev):
+    n, primes, batch = 1024, 2, 6
+    qs = agx.find_primes(60, n, primes)
+    plan = agx.Plan(n, qs)
+    whole = dev.empty(primes * batch * n)
+    plan.fill_synthetic(whole.data_ptr(), batch, 0, 42, dev.stream)
+    w = dev.to_host(whole).reshape(primes, batch, n)
+    for p in range(primes):
+        assert (w[p] < qs[p]).all()
+    part = dev.empty(primes * 2 * n)
+    plan.fill_synthetic(part.data_ptr(), 2, 3, 42, dev.stream)  # polys 3,4
+    assert np.array_equal(dev.to_host(part).reshape(primes, 2, n), w[:, 3:5, :])
+    assert len(np.unique(w)) > w.size * 0.99
+    plan.close()
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json configurations at full size, through size-independent properties
+# ---------------------------------------------------------------------------------------
+def _mod_add(a, b, q):
+    s = a + b  # < 2^61 + 2^61 fits
+    return np.where(s >= q, s - np.uint64(q), s)
+
+
+def test_config3_full_size_properties(agx, orc, dev):
+    """n=4096, 4-prime RNS, batch=4096 (the roofline run): linearity, round trip, and a sample
+    of frames against the oracle"""
+    n, primes, batch = 4096, 4, 4096
+    qs = agx.find_primes(60, n, primes)
+    plan = agx.Plan(n, qs)
+    total = primes * batch * n
+    d_a, d_b = dev.empty(total), dev.empty(total)
+    plan.fill_synthetic(d_a.data_ptr(), batch, 0, 1, dev.stream)
+    plan.fill_synthetic(d_b.data_ptr(), batch, 0, 2, dev.stream)
+    a, b = dev.to_host(d_a), dev.to_host(d_b)
+    s = np.concatenate([_mod_add(a[p * batch * n:(p + 1) * batch * n], b[p * batch * n:(p + 1) * batch * n], qs[p]) for p in range(primes)])
+    d_s = dev.to_device(s)
+    d_fa, d_fb = dev.empty(total), dev.empty(total)
+    plan.forward(d_a.data_ptr(), d_fa.data_ptr(), batch, dev.stream)
+    plan.forward(d_b.data_ptr(), d_fb.data_ptr(), batch, dev.stream)
+    plan.forward(d_s.data_ptr(), d_s.data_ptr(), batch, dev.stream)
+    fa, fb, fs = dev.to_host(d_fa), dev.to_host(d_fb), dev.to_host(d_s)
+    for p in range(primes):
+        sl = slice(p * batch * n, (p + 1) * batch * n)
+        assert (fa[sl] < qs[p]).all()
+        assert np.array_equal(_mod_add(fa[sl], fb[sl], qs[p]), fs[sl]), "NTT(a+b) != NTT(a)+NTT(b)"
+    plan.inverse(d_fa.data_ptr(), d_fa.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_fa), a), "INTT(NTT(a)) != a"
+    for p in range(primes):
+        tw, pre = orc.make_tables(qs[p], plan.psi(p), n)
+        for f in (0, 1, 2047, 4095):
+            sl = slice((p * batch + f) * n, (p * batch + f + 1) * n)
+            assert np.array_equal(orc.forward(a[sl], qs[p], tw, pre, n), fa[sl])
+            assert np.array_equal(orc.forward(b[sl], qs[p], tw, pre, n), fb[sl])
+    plan.close()
+
+
+def test_config2_single_60bit_forward_inverse(agx, orc, dev):
+    """n=4096, one 60-bit modulus, batch=1 forward+inverse, bit-exact vs CPU"""
+    n = 4096
+    q = agx.find_primes(60, n)[0]
+    plan = agx.Plan(n, [q])
+    tw, pre = orc.make_tables(q, plan.psi(0), n)
+    x = orc.fill_splitmix(n, 42, q)
+    d = dev.to_device(x)
+    plan.forward(d.data_ptr(), d.data_ptr(), 1, dev.stream)
+    assert np.array_equal(dev.to_host(d), orc.forward(x, q, tw, pre, n))
+    plan.inverse(d.data_ptr(), d.data_ptr(), 1, dev.stream)
+    assert np.array_equal(dev.to_host(d), x)
+    plan.close()
+
+
+def test_config4_shape_one_gpu_slice(agx, orc, dev):
+    """n=16384, 8-prime RNS; one GPU's slice is cut down to batch 256 here (full batch 65536 is
+    64 GiB over 8 GPUs): round trip plus sampled frames against the oracle"""
+    n, primes, batch = 16384, 8, 256
+    qs = agx.find_primes(60, n, primes)
+    plan = agx.Plan(n, qs)
+    total = primes * batch * n
+    d_a = dev.empty(total)
+    plan.fill_synthetic(d_a.data_ptr(), batch, 0, 3, dev.stream)
+    a = dev.to_host(d_a)
+    d_f = dev.empty(total)
+    plan.forward(d_a.data_ptr(), d_f.data_ptr(), batch, dev.stream)
+    f = dev.to_host(d_f)
+    for p in (0, 7):
+        tw, pre = orc.make_tables(qs[p], plan.psi(p), n)
+        for k in (0, 255):
+            sl = slice((p * batch + k) * n, (p * batch + k + 1) * n)
+            assert np.array_equal(orc.forward(a[sl], qs[p], tw, pre, n), f[sl])
+    plan.inverse(d_f.data_ptr(), d_f.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_f), a)
+    plan.close()
+
+
+def test_config5_polymul_32768(agx, orc, dev):
+    """n=32768 full poly-mul (NTT -> pointwise -> INTT): convolution theorem checked through
+    X^j * b = negacyclic shift of b, and against the oracle pipeline on one frame"""
+    n, batch = 32768, 4
+    q = agx.find_primes(60, n)[0]
+    plan = agx.Plan(n, [q])
+    rng = np.random.default_rng(99)
+    b = rand_coeffs(rng, batch * n, q)
+    a = np.zeros(batch * n, dtype=np.uint64)
+    shifts = [0, 1, 12345, n - 1]
+    for f, j in enumerate(shifts):
+        a[f * n + j] = 1
+    d_a, d_b, d_c, d_s = dev.to_device(a), dev.to_device(b), dev.empty(a.size), dev.empty(a.size)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), batch, dev.stream)
+    c = dev.to_host(d_c)
+    for f, j in enumerate(shifts):
+        bf = b[f * n:(f + 1) * n]
+        want = np.concatenate([(np.uint64(q) - bf[n - j:]) % np.uint64(q), bf[:n - j]]) if j else bf
+        assert np.array_equal(c[f * n:(f + 1) * n], want)
+    tw, pre = orc.make_tables(q, plan.psi(0), n)
+    itw, _ = orc.make_inv_tables(q, plan.psi(0), n)
+    a2 = rand_coeffs(rng, n, q)
+    d_a2 = dev.to_device(np.concatenate([a2, a[n:]]))
+    plan.polymul(d_a2.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), batch, dev.stream)
+    want = orc.inverse(orc.pointwise(orc.forward(a2, q, tw, pre, n), orc.forward(b[:n], q, tw, pre, n), q), q, itw, n)
+    assert np.array_equal(dev.to_host(d_c)[:n], want)
+    plan.close()

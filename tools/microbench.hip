@@ -1,0 +1,225 @@
+// tools/microbench.hip -- box calibration for the NTT kernel design.
+// Measures (i) issue cost of the integer instructions a Harvey/Shoup butterfly is made of,
+// (ii) streaming copy bandwidth for the access shapes the NTT kernels use.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <string>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+enum Op { ADD32, MAD64, MAD64_SGPR, MULLO, MULHI, MAD24, MULHI24, LSHLADD64, ADDC_PAIR, CMP_CND64, FMA64, DPP_MOV, PERMSWAP, BPERMUTE, SUB_PAIR, NOPS };
+static const char* op_name[] = {"v_add_u32", "v_mad_u64_u32", "v_mad_u64_u32(sgpr src)", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
+    "v_lshl_add_u64", "v_add_co+v_addc_co (pair)", "v_cmp_ge_u64+2cndmask (triple)", "v_fma_f64", "v_mov_b32 dpp quad_perm", "v_permlane32_swap", "ds_bpermute_b32", "v_sub_co+v_subb_co (pair)"};
+
+// 8 independent chains per asm block, 2 blocks per loop iteration = 16 "units" per iteration
+template <int OP>
+__global__ void __launch_bounds__(256) alu_kernel(uint64_t* out, int iters, uint32_t sval) {
+    uint32_t a = threadIdx.x * 2654435761u + 12345u, b = (threadIdx.x ^ 0x5a5a5a5au) | 1u;
+    uint64_t c0 = a, c1 = b, c2 = a + 1, c3 = b + 2, c4 = a + 3, c5 = b + 4, c6 = a + 5, c7 = b + 6;
+    double d0 = a, d1 = b, d2 = 1.5, d3 = 2.5, d4 = 3.5, d5 = 4.5, d6 = 5.5, d7 = 6.5, da = 1.0000001, db = 1e-9;
+    uint32_t x0 = a, x1 = b, x2 = a ^ b, x3 = a + b, x4 = a - b, x5 = a * 3, x6 = b * 5, x7 = a * 7;
+    uint32_t s = __builtin_amdgcn_readfirstlane(sval);
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            if constexpr (OP == ADD32) {
+                asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                             "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+            } else if constexpr (OP == MAD64) {
+                asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                             "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b) : "vcc");
+            } else if constexpr (OP == MAD64_SGPR) {
+                asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                             "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "s"(s), "v"(b) : "vcc");
+            } else if constexpr (OP == MULLO) {
+                asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                             "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+            } else if constexpr (OP == MULHI) {
+                asm volatile("v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n"
+                             "v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+            } else if constexpr (OP == MAD24) {
+                asm volatile("v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n"
+                             "v_mad_u32_u24 %4, %4, %8, %9\n v_mad_u32_u24 %5, %5, %8, %9\n v_mad_u32_u24 %6, %6, %8, %9\n v_mad_u32_u24 %7, %7, %8, %9\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b), "v"(a));
+            } else if constexpr (OP == MULHI24) {
+                asm volatile("v_mul_hi_u32_u24 %0, %0, %8\n v_mul_hi_u32_u24 %1, %1, %8\n v_mul_hi_u32_u24 %2, %2, %8\n v_mul_hi_u32_u24 %3, %3, %8\n"
+                             "v_mul_hi_u32_u24 %4, %4, %8\n v_mul_hi_u32_u24 %5, %5, %8\n v_mul_hi_u32_u24 %6, %6, %8\n v_mul_hi_u32_u24 %7, %7, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+            } else if constexpr (OP == LSHLADD64) {
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n"
+                             "v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8\n"
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(c0 | 1));
+            } else if constexpr (OP == ADDC_PAIR) {
+                asm volatile("v_add_co_u32 %0, vcc, %0, %8\n v_addc_co_u32 %1, vcc, %1, %8, vcc\n v_add_co_u32 %2, vcc, %2, %8\n v_addc_co_u32 %3, vcc, %3, %8, vcc\n"
+                             "v_add_co_u32 %4, vcc, %4, %8\n v_addc_co_u32 %5, vcc, %5, %8, vcc\n v_add_co_u32 %6, vcc, %6, %8\n v_addc_co_u32 %7, vcc, %7, %8, vcc\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b) : "vcc");
+            } else if constexpr (OP == SUB_PAIR) {
+                asm volatile("v_sub_co_u32 %0, vcc, %0, %8\n v_subb_co_u32 %1, vcc, %1, %8, vcc\n v_sub_co_u32 %2, vcc, %2, %8\n v_subb_co_u32 %3, vcc, %3, %8, vcc\n"
+                             "v_sub_co_u32 %4, vcc, %4, %8\n v_subb_co_u32 %5, vcc, %5, %8, vcc\n v_sub_co_u32 %6, vcc, %6, %8\n v_subb_co_u32 %7, vcc, %7, %8, vcc\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b) : "vcc");
+            } else if constexpr (OP == CMP_CND64) {
+                // 4 x (64-bit compare + two selects) per block: count as 4 triples = 12 instr; reported per instruction
+                asm volatile("v_cmp_ge_u64 vcc, %[c0], %[c1]\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n"
+                             "v_cmp_ge_u64 vcc, %[c2], %[c3]\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cmp_ge_u64 vcc, %[c4], %[c5]\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n"
+                             "v_cmp_ge_u64 vcc, %[c6], %[c7]\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                             : "v"(b), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [c7] "v"(c7) : "vcc");
+            } else if constexpr (OP == FMA64) {
+                asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                             "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(da), "v"(db));
+            } else if constexpr (OP == DPP_MOV) {
+                asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %6, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            } else if constexpr (OP == PERMSWAP) {
+                asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                             "v_permlane32_swap_b32 %1, %2\n v_permlane32_swap_b32 %3, %4\n v_permlane32_swap_b32 %5, %6\n v_permlane32_swap_b32 %7, %0\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            } else if constexpr (OP == BPERMUTE) {
+                uint32_t addr = ((threadIdx.x ^ 1) & 63) << 2;
+                asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n"
+                             "ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(addr));
+            }
+        }
+    }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    uint64_t sink = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7 ^ x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7 ^ (uint64_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+    size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) out[wave] = t1 - t0;
+    if (sink == 0x1234567890abcdefull) out[wave] = sink;  // keep values live
+}
+
+template <int OP>
+static void run_alu(uint64_t* d_out, int waves_per_simd) {
+    const int iters = 4096;
+    const int blocks = 256 * waves_per_simd;
+    std::vector<uint64_t> h(blocks * 4);
+    alu_kernel<OP><<<blocks, 256>>>(d_out, 64, 7u);  // warm
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    alu_kernel<OP><<<blocks, 256>>>(d_out, iters, 7u);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(h.begin(), h.end());
+    double med = (double)h[h.size() / 2];
+    double instr_per_wave = (double)iters * 16.0 * (OP == CMP_CND64 ? 12.0 / 16.0 : 1.0);
+    // s_memtime ticks at a constant 100 MHz-derived rate on some parts; report both tick-based and wall-based figures
+    double wall_cyc_at_2p4 = ms * 1e-3 * 2.4e9;
+    printf("  %-34s waves/SIMD=%d  ticks/instr/wave=%7.3f  ticks/instr/SIMD=%7.3f  wall: %8.3f ms -> %6.3f clk(2.4GHz)/instr/SIMD\n",
+           op_name[OP], waves_per_simd, med / instr_per_wave, med / instr_per_wave / waves_per_simd, ms,
+           wall_cyc_at_2p4 / instr_per_wave / waves_per_simd);
+}
+
+// ---------------------------------------------------------------- bandwidth
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(256) copy16(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t n16) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) out[i] = in[i];
+}
+__global__ void __launch_bounds__(256) copy8(const u32x2* __restrict__ in, u32x2* __restrict__ out, size_t n8) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) out[i] = in[i];
+}
+// one block per 32 KiB slab (the n=4096 frame shape): every thread loads 8 x 16 B up front then stores
+__global__ void __launch_bounds__(256) copy_slab(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t slabs) {
+    for (size_t s = blockIdx.x; s < slabs; s += gridDim.x) {
+        const u32x4* p = in + s * 2048; u32x4* o = out + s * 2048;
+        u32x4 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = p[threadIdx.x + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[threadIdx.x + 256 * k] = r[k];
+    }
+}
+// reads coalesced, stores 16 B per lane at a lane stride of LS bytes (thread-contiguous runs): the
+// store shape of a register-blocked last pass that keeps 2^R consecutive coefficients per lane
+template <int LS>
+__global__ void __launch_bounds__(256) copy_lane_strided_store(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t slabs) {
+    constexpr int PER = LS / 16;             // 16-B chunks per lane run
+    constexpr int LANES = 2048 / PER;        // lanes needed per 32 KiB slab
+    for (size_t s = blockIdx.x; s < slabs; s += gridDim.x) {
+        const u32x4* p = in + s * 2048; u32x4* o = out + s * 2048;
+        if (LANES >= 256) {
+            u32x4 r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = p[threadIdx.x + 256 * k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[threadIdx.x * 8 + k] = r[k];
+        } else if ((int)threadIdx.x < LANES) {
+            u32x4 r[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) r[k] = p[threadIdx.x + LANES * k];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) o[threadIdx.x * PER + k] = r[k];
+        }
+    }
+}
+
+template <typename F>
+static void time_bw(const char* name, size_t bytes_moved, F launch) {
+    launch(); CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 10;
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  %-44s %8.1f GB/s (read+write)\n", name, (double)bytes_moved * reps / (ms * 1e-3) / 1e9);
+}
+
+int main(int argc, char** argv) {
+    bool do_alu = true, do_bw = true;
+    if (argc > 1 && std::string(argv[1]) == "alu") do_bw = false;
+    if (argc > 1 && std::string(argv[1]) == "bw") do_alu = false;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s  CUs=%d  clock=%d kHz  L2=%d  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate, prop.l2CacheSize, prop.sharedMemPerBlock);
+    if (do_alu) {
+        uint64_t* d_out; CK(hipMalloc(&d_out, 256 * 8 * 4 * 8));
+        printf("ALU issue cost (16 independent chains per loop body; lower = faster)\n");
+        for (int w : {1, 2, 4}) {
+            run_alu<ADD32>(d_out, w); run_alu<MAD64>(d_out, w); run_alu<MAD64_SGPR>(d_out, w); run_alu<MULLO>(d_out, w); run_alu<MULHI>(d_out, w);
+            run_alu<MAD24>(d_out, w); run_alu<MULHI24>(d_out, w); run_alu<LSHLADD64>(d_out, w); run_alu<ADDC_PAIR>(d_out, w); run_alu<SUB_PAIR>(d_out, w);
+            run_alu<CMP_CND64>(d_out, w); run_alu<FMA64>(d_out, w); run_alu<DPP_MOV>(d_out, w); run_alu<PERMSWAP>(d_out, w); run_alu<BPERMUTE>(d_out, w);
+            printf("\n");
+        }
+        CK(hipFree(d_out));
+    }
+    if (do_bw) {
+        const size_t bytes = 2ull << 30;  // 2 GiB in + 2 GiB out: far beyond the 256 MiB Infinity Cache
+        void *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
+        CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
+        printf("streaming copy, 2 GiB -> 2 GiB\n");
+        for (int g : {2048, 4096, 8192})
+            time_bw(("copy16 grid-stride grid=" + std::to_string(g)).c_str(), 2 * bytes, [&] { copy16<<<g, 256>>>((const u32x4*)a, (u32x4*)b, bytes / 16); });
+        time_bw("copy8 grid-stride grid=4096", 2 * bytes, [&] { copy8<<<4096, 256>>>((const u32x2*)a, (u32x2*)b, bytes / 8); });
+        size_t slabs = bytes / 32768;
+        time_bw("copy_slab (1 block per 32 KiB slab)", 2 * bytes, [&] { copy_slab<<<(unsigned)slabs, 256>>>((const u32x4*)a, (u32x4*)b, slabs); });
+        time_bw("copy_slab grid=2048 looped", 2 * bytes, [&] { copy_slab<<<2048, 256>>>((const u32x4*)a, (u32x4*)b, slabs); });
+        time_bw("store lane-stride 128 B (16 coeff/lane)", 2 * bytes, [&] { copy_lane_strided_store<128><<<(unsigned)slabs, 256>>>((const u32x4*)a, (u32x4*)b, slabs); });
+        time_bw("store lane-stride 256 B (32 coeff/lane)", 2 * bytes, [&] { copy_lane_strided_store<256><<<(unsigned)slabs, 256>>>((const u32x4*)a, (u32x4*)b, slabs); });
+        time_bw("store lane-stride 512 B (64 coeff/lane)", 2 * bytes, [&] { copy_lane_strided_store<512><<<(unsigned)slabs, 256>>>((const u32x4*)a, (u32x4*)b, slabs); });
+        CK(hipFree(a)); CK(hipFree(b));
+    }
+    return 0;
+}
