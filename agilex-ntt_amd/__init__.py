@@ -71,12 +71,29 @@ def build(verbose=False):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) and ask for
+    it by file name, so a process that loaded /opt/rocm's copy first ends up with two HIP
+    runtimes: torch's device pointers and streams would then mean nothing to this library.
+    Loading torch's copy by path before libagxntt.so makes both resolve to the same runtime,
+    whatever the import order.  Without torch installed the system runtime is used."""
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib():
     """Load libagxntt.so.  Raises if it has not been built: there is no fallback path."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `make -C {_HERE} build` (or __graft_entry__.build())")
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in ABI.items():
             fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
