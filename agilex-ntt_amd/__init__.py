@@ -18,6 +18,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 AGX_OK = 0
 VARIANT_AUTO, VARIANT_LDS_RADIX2, VARIANT_REGBLOCK = 0, 1, 2
+VARIANT_REGBLOCK_BASE = 256  # + registry index: A/B measurements only
 
 _u64 = ctypes.c_uint64
 _u32 = ctypes.c_uint32

@@ -226,8 +226,34 @@ int agx_ntt_plan_destroy(agx_ntt_plan* plan) {
 
 int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant) {
     if (!plan) return AGX_ERR_NULL_POINTER;
+    int config_id = -1;
+    if (variant >= AGX_VARIANT_REGBLOCK_BASE) {
+        config_id = variant - AGX_VARIANT_REGBLOCK_BASE;
+        variant = AGX_VARIANT_REGBLOCK;
+    }
     if (variant != AGX_VARIANT_AUTO && variant != AGX_VARIANT_LDS_RADIX2 && variant != AGX_VARIANT_REGBLOCK) return AGX_ERR_BAD_ARGUMENT;
-    if (variant == AGX_VARIANT_REGBLOCK && !plan->rb.valid()) return AGX_ERR_BAD_SIZE;
+    if (variant == AGX_VARIANT_REGBLOCK || variant == AGX_VARIANT_AUTO) {
+        // (re)build the pass tables for the requested kernel configuration
+        const regblock_layout rb = regblock_choose(plan->n, config_id);
+        if (!rb.valid()) {
+            if (variant == AGX_VARIANT_REGBLOCK) return AGX_ERR_BAD_SIZE;
+        } else if (rb.config_id != plan->rb.config_id) {
+            std::vector<ulonglong2> tw((size_t)plan->num_primes * plan->n), rb_pairs;
+            AGX_HIP(hipMemcpy(tw.data(), plan->d_tw, tw.size() * sizeof(ulonglong2), hipMemcpyDeviceToHost));
+            std::vector<uint64_t> w(plan->n), wp(plan->n);
+            for (uint32_t k = 0; k < plan->num_primes; ++k) {
+                for (uint32_t j = 0; j < plan->n; ++j) { w[j] = tw[(size_t)k * plan->n + j].x; wp[j] = tw[(size_t)k * plan->n + j].y; }
+                regblock_build_table(rb, w.data(), wp.data(), rb_pairs);
+            }
+            ulonglong2* d_new = nullptr;
+            int rc = upload(&d_new, rb_pairs);
+            if (rc != AGX_OK) return rc;
+            AGX_HIP(hipDeviceSynchronize());
+            if (plan->d_tw_rb) (void)hipFree(plan->d_tw_rb);
+            plan->d_tw_rb = d_new;
+            plan->rb = rb;
+        }
+    }
     plan->variant = variant;
     return AGX_OK;
 }

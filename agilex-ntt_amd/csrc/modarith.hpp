@@ -58,4 +58,123 @@ __device__ __forceinline__ uint64_t mul_mod_barrett(uint64_t a, uint64_t b, cons
     return csub(r, k.q);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Hand-selected instruction forms for the throughput kernels.
+//
+// Box calibration (profiles/r01_microbench_box_calibration.txt): on gfx950 every VOP3 integer
+// op (v_mad_u64_u32, v_mul_lo/hi_u32, v_add3, v_lshl_add_u64, carry adds) issues at about half
+// the rate of a plain VOP2 add, so a butterfly's cost is its instruction COUNT.  hipcc lowers
+// the portable butterfly above to ~32 VALU instructions (v_mul_lo + v_add3 cross terms,
+// v_mov pairs to zero-extend 32-bit partial products, 64-bit compare + 2 selects); the forms
+// below need about 20 (fast) / 27 (exact).  They stay in C++ (two opaque values steer hipcc's
+// instruction selection) because hipcc pads every inline-asm instruction with an s_nop.
+// ---------------------------------------------------------------------------------------
+
+// a*b + c with a,b 32-bit: hipcc selects v_mad_u64_u32 for this shape
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+__device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b) { return (uint64_t)a * b; }
+
+// The value 1 in a form the optimiser cannot see through: c + zext(a) is then one
+// v_mad_u64_u32 (a * 1 + c) instead of a v_mov (to build the {a,0} pair) plus a 64-bit add.
+template <int TAG>   // identical asm statements would be merged: give each value its own text
+__device__ __forceinline__ uint32_t opaque_one() {
+    uint32_t one;
+    if constexpr (TAG == 0) asm("s_mov_b32 %0, 1" : "=s"(one));
+    else asm("s_movk_i32 %0, 0x1" : "=s"(one));
+    return one;
+}
+// Two such adds in one sum must use DIFFERENT opaque ones, or hipcc factors them back into
+// (a + b) * one and rebuilds the register pairs this is meant to avoid.
+__device__ __forceinline__ uint64_t add64_32(uint64_t c, uint32_t a, uint32_t one) { return (uint64_t)a * one + c; }
+
+// hide how a wave-uniform 64-bit constant was derived (x + opaque(-m) stays ONE v_lshl_add_u64
+// instead of becoming a v_sub_co/v_subb pair)
+__device__ __forceinline__ uint64_t opaque_sgpr64(uint64_t v) {
+    asm("" : "+s"(v));
+    return v;
+}
+
+// Keeps all 64 bits of v live, so a multiply-add chain of which only the low word is used is
+// not demoted to v_mul_lo_u32 + v_add3_u32 pairs (two instructions per term instead of one).
+__device__ __forceinline__ uint64_t keep64(uint64_t v) {
+    asm("" : "+v"(v));
+    return v;
+}
+
+// per-prime constants of the throughput kernels (wave-uniform: live in SGPRs)
+struct bf_consts {
+    uint64_t q;
+    uint64_t nq;     // 2^64 - q
+    uint64_t m;      // lazy-range step: 2q (exact arithmetic) or 4q (fast arithmetic)
+    uint64_t nm;     // 2^64 - m
+    uint32_t one_a, one_b;  // two separate opaque_one() values (see add64_32)
+};
+
+// x in [0,2m) -> x - (x >= m ? m : 0) through the sign of x - m; needs 2m <= 2^63... see callers
+__device__ __forceinline__ uint64_t csub_sign(uint64_t x, const bf_consts& k) {
+    const uint64_t d = x + k.nm;
+    const uint32_t neg = (uint32_t)((int32_t)(uint32_t)(d >> 32) >> 31);  // all ones when x < m
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 add;
+    add.x = neg & (uint32_t)k.m;
+    add.y = neg & (uint32_t)(k.m >> 32);
+    return d + __builtin_bit_cast(uint64_t, add);
+}
+
+// x' = tx + w*y - c*q (mod 2^64), the whole right-hand side in 6 multiply-adds + 1 add:
+// the low words accumulate straight onto tx, the four cross products only matter mod 2^32
+__device__ __forceinline__ uint64_t fold_product(uint64_t tx, uint64_t y, uint64_t w, uint64_t c, const bf_consts& k) {
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32), nq0 = (uint32_t)k.nq, nq1 = (uint32_t)(k.nq >> 32);
+    uint64_t acc = mad64(w0, y0, tx);
+    acc = mad64(nq0, c0, acc);
+    uint64_t z = mul64(w0, y1);
+    z = mad64(w1, y0, z);
+    z = mad64(nq1, c0, z);
+    z = keep64(mad64(nq0, c1, z));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 a = __builtin_bit_cast(u32x2, acc);
+    a.y += (uint32_t)z;
+    return __builtin_bit_cast(uint64_t, a);
+}
+
+// EXACT arithmetic: the reference's butterfly (src/kernel/ntt.cpp:331-369) value for value --
+// c = floor(y*w'/2^64) exactly, coefficients in [0,4q), any q < 2^62.
+__device__ __forceinline__ void ct_butterfly_exact(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k) {
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
+    const uint64_t tx = csub(x, k.m);                                       // m = 2q
+    const uint32_t t = __umulhi(y0, p0);
+    const uint64_t m1 = add64_32(mul64(p1, y0), t, k.one_a);                 // y0*p1 + hi(y0*p0)
+    const uint64_t m2 = add64_32(mul64(p0, y1), (uint32_t)m1, k.one_b);      // y1*p0 + lo(m1)
+    uint64_t c = add64_32(mul64(p1, y1), (uint32_t)(m1 >> 32), k.one_a);
+    c = add64_32(c, (uint32_t)(m2 >> 32), k.one_b);
+    const uint64_t xn = fold_product(tx, y, w, c, k);
+    y = (tx << 1) + k.m - xn;                                               // tx + 2q - Q
+    x = xn;
+}
+
+// FAST arithmetic for q <= 2^61: quotient estimate c~ = y1*p1 + hi(y0*p1) + hi(y1*p0) is low by
+// at most 2, so Q~ = w*y - c~*q lies in [0,4q); coefficients are kept in [0,8q) with m = 4q:
+//   tx = x - (x >= 4q ? 4q : 0) < 4q,  x' = tx + Q~ < 8q,  y' = tx + 4q - Q~ in (0,8q).
+// Same residues as the exact form at every stage, so the fully reduced outputs are identical.
+__device__ __forceinline__ void ct_butterfly_fast(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k) {
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
+    const uint64_t tx = csub_sign(x, k);                                    // m = 4q <= 2^63
+    uint64_t c = mul64(p1, y1);
+    c = add64_32(c, __umulhi(y0, p1), k.one_a);
+    c = add64_32(c, __umulhi(y1, p0), k.one_b);
+    const uint64_t xn = fold_product(tx, y, w, c, k);
+    y = (tx << 1) + k.m - xn;                                               // tx + 4q - Q~
+    x = xn;
+}
+
+// [0,2m) -> [0,q) at the last stage (m = 2q: two steps; m = 4q: three)
+template <bool FAST>
+__device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k) {
+    if constexpr (FAST) v = csub(v, k.m);
+    v = csub(v, k.q << 1);
+    return csub(v, k.q);
+}
+
 }  // namespace agx

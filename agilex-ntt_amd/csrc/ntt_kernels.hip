@@ -215,8 +215,8 @@ struct rb_geom {
 
 __device__ __forceinline__ constexpr uint32_t lds_pad(uint32_t e) { return e + (e >> 4); }
 
-template <int L, int R, int PPB, bool STAGE_OUT>
-__global__ void __launch_bounds__((1 << (L - R)) * PPB)
+template <int L, int R, int PPB, bool STAGE_OUT, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 fwd_regblock(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
              const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
              uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
@@ -297,6 +297,160 @@ fwd_regblock(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
 }
 
 // ---------------------------------------------------------------------------------------
+// register-blocked forward kernel, second generation (the throughput path).
+//
+// Same pass structure as fwd_regblock; what changed, each item from a measurement:
+//  * hand-selected butterfly forms (modarith.hpp): 20 VALU (fast, q <= 2^61) / 27 (exact)
+//    instead of ~32, because VOP3 integer ops all issue at half rate on gfx950;
+//  * passes whose twiddle column depends only on the wave index (rlo >= 6) read their twiddles
+//    with scalar loads into SGPRs: no VGPRs, no VALU, no vector-memory traffic for them;
+//  * an exchange that only moves coefficients between lanes of the same wave needs no
+//    workgroup barrier (one wave's LDS operations execute in program order); which exchanges
+//    those are is decided at compile time by exchange_is_wave_local();
+//  * XOR-swizzled LDS image instead of padding: conflict-free for the contiguous, the
+//    stride-8 and the mixed (low 3 bits + bits 6..8) lane patterns the R = 3 passes produce,
+//    and exactly n*8 bytes per frame;
+//  * results leave through the LDS image as coalesced stores (each wave owns a contiguous
+//    chunk of the frame after the first exchange).
+// ---------------------------------------------------------------------------------------
+template <int L, int R>
+struct rb2_geom : rb_geom<L, R> {
+    using G = rb_geom<L, R>;
+    static constexpr uint32_t elem(int p, uint32_t tid, uint32_t r) {
+        const int rlo = G::rlo(p);
+        return (tid & ((1u << rlo) - 1u)) | (r << rlo) | ((tid >> rlo) << (rlo + R));
+    }
+    static constexpr uint32_t owner(int p, uint32_t e) {
+        const int rlo = G::rlo(p);
+        return (e & ((1u << rlo) - 1u)) | ((e >> (rlo + R)) << rlo);
+    }
+    // does the exchange between pass p and p+1 keep every coefficient inside one wave?
+    static constexpr bool exchange_is_wave_local(int p) {
+        for (uint32_t tid = 0; tid < (uint32_t)G::T; ++tid)
+            for (uint32_t r = 0; r < (uint32_t)G::C; ++r)
+                if ((owner(p + 1, elem(p, tid, r)) >> 6) != (tid >> 6)) return false;
+        return true;
+    }
+    // after the last pass, does every wave hold one contiguous block of 64*C coefficients?
+    static constexpr bool last_pass_wave_contiguous() { return G::rlo(G::NP - 1) == 0 && G::T >= 64; }
+};
+
+// LDS image index of coefficient e: XOR-swizzle of the low five bits (one 256-byte bank row of
+// ds_read_b64) by bits 5..8, so that every lane pattern of the passes spreads over the banks
+__device__ __forceinline__ constexpr uint32_t lds_swz(uint32_t e) {
+    return e ^ ((e >> 5) & 7u) ^ (((e >> 6) & 3u) << 3);
+}
+
+// wave-uniform table entry through the constant address space: a scalar load into SGPRs
+__device__ __forceinline__ twpair load_uniform(const twpair* p) {
+    typedef const uint64_t __attribute__((address_space(4))) * const_ptr;
+    const_ptr c = (const_ptr)(uintptr_t)p;
+    twpair r;
+    r.x = c[0];
+    r.y = c[1];
+    return r;
+}
+
+template <int L, int R, int PPB, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
+fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+        const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
+        uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
+        int64_t prime_stride, int64_t poly_stride) {
+    using G = rb2_geom<L, R>;
+    constexpr int C = G::C, T = G::T, NP = G::NP;
+    constexpr bool FAST = ARITH == 1;
+    static_assert(T >= 64, "one frame must span whole waves");
+    uint64_t* lds = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+
+    const uint32_t tid = threadIdx.x & (T - 1);
+    const uint32_t slot = threadIdx.x / T;
+    uint64_t fx = (uint64_t)blockIdx.x * PPB + slot;
+    const bool live = fx < frames_x;
+    if (!live) fx = frames_x - 1;
+    const uint32_t prime = blockIdx.y;
+    const uint64_t poly = fx >> split_log;
+    const uint32_t blk = (uint32_t)(fx & ((1u << split_log) - 1u));
+    bf_consts k;
+    k.q = consts[prime].q;
+    k.nq = 0 - k.q;
+    k.m = FAST ? (k.q << 2) : (k.q << 1);
+    k.nm = opaque_sgpr64(0 - k.m);
+    k.one_a = opaque_one<0>();
+    k.one_b = opaque_one<1>();
+    const twpair* tbl = tw_rb + (size_t)prime * pairs_per_prime;
+    const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)blk << L);
+    uint64_t* slab = lds + ((size_t)slot << L);
+
+    uint64_t x[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) x[r] = in[base + tid + (uint32_t)r * T];
+
+    static_for<0, NP>([&](auto P) {
+        constexpr int p = P;
+        constexpr int rlo = G::rlo(p), hi = G::hi(p), H = G::H(p);
+        constexpr bool uniform = rlo >= 6;    // tid >> rlo is the same for the 64 lanes of a wave
+        const uint32_t low = tid & ((1u << rlo) - 1u), high = tid >> rlo;
+        const uint32_t sbase = lds_swz(low | (high << (rlo + R)));
+        if constexpr (p > 0) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) x[r] = slab[sbase ^ lds_swz((uint32_t)r << rlo)];
+        }
+        const uint32_t hcol = uniform ? (uint32_t)__builtin_amdgcn_readfirstlane((int)high) : high;
+        const twpair* col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + (H == 1 ? 0u : hcol);
+        const uint32_t hstride = (uint32_t)H << split_log;
+        static_for<0, hi - rlo + 1>([&](auto S) {
+            constexpr int rb = (hi - rlo) - S;
+            constexpr int kk = R - 1 - rb;
+            constexpr bool last_stage = (rlo + rb) == 0;
+#pragma unroll
+            for (int r0 = 0; r0 < C; ++r0) {
+                if ((r0 >> rb) & 1) continue;
+                const int r1 = r0 | (1 << rb);
+                const int j = (1 << kk) + (r0 >> (rb + 1));
+                twpair w;
+                if constexpr (uniform) w = load_uniform(col + (size_t)j * hstride);   // s_load_dwordx4
+                else w = col[(size_t)j * hstride];
+                if constexpr (FAST) ct_butterfly_fast(x[r0], x[r1], w.x, w.y, k);
+                else ct_butterfly_exact(x[r0], x[r1], w.x, w.y, k);
+                if constexpr (last_stage) {
+                    x[r0] = reduce_final<FAST>(x[r0], k);
+                    x[r1] = reduce_final<FAST>(x[r1], k);
+                }
+            }
+        });
+        if constexpr (p < NP - 1) {
+            constexpr bool local_next = G::exchange_is_wave_local(p);
+            constexpr bool local_prev = p > 0 && G::exchange_is_wave_local(p - 1);
+            // the slab region this thread overwrites was last read in this pass: by this wave only
+            // if the previous exchange was wave-local, by any wave otherwise
+            if constexpr (p > 0 && !local_prev) __syncthreads();
+#pragma unroll
+            for (int r = 0; r < C; ++r) slab[sbase ^ lds_swz((uint32_t)r << rlo)] = x[r];
+            if constexpr (!local_next) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
+        }
+    });
+
+    // last pass: rlo = 0, thread holds coefficients [tid*C, tid*C + C); a wave holds 64*C
+    // contiguous ones.  Through the image once more so that global stores are lane-contiguous.
+    static_assert(G::last_pass_wave_contiguous(), "store path assumes a wave-contiguous last pass");
+    constexpr bool prev_local = NP > 1 && G::exchange_is_wave_local(NP - 2);
+    if constexpr (NP > 1 && !prev_local) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < C; ++r) slab[lds_swz((tid << R) | (uint32_t)r)] = x[r];
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+        const uint32_t wbase = (tid >> 6) << (6 + R), lane = tid & 63u;
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            const uint32_t e = wbase + lane + 64u * (uint32_t)r;
+            out[base + e] = slab[lds_swz(e)];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // pointwise product and synthetic fill
 // ---------------------------------------------------------------------------------------
 __global__ void pointwise_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ c,
@@ -338,17 +492,20 @@ __global__ void fill_kernel(uint64_t* __restrict__ out, const prime_consts* __re
 // ---------------------------------------------------------------------------------------
 namespace {
 
-struct rb_config { int log_local; int r; int ppb; };
-// one tuned configuration per workgroup-resident size
-constexpr rb_config kRbConfigs[] = {
-    {10, 4, 4}, {11, 4, 2}, {12, 4, 1}, {13, 5, 1}, {14, 5, 1},
+// ---- registry of register-blocked configurations -------------------------------------
+// id 0..: first entry for a given log_local is the tuned default; the others are kept for
+// A/B measurements (agx_ntt_plan_set_variant(plan, AGX_VARIANT_REGBLOCK_BASE + id)).
+struct rb_entry {
+    int id, log_local, r, ppb;
+    bool stage_out;
+    int min_waves;
+    uint32_t table_pairs;   // per sub-block
+    size_t lds_bytes;
+    void (*build)(const regblock_layout&, const uint64_t*, const uint64_t*, std::vector<ulonglong2>&);
+    hipError_t (*launch)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    hipError_t (*init)();
+    int arith;   // 0: exact (reference op sequence, q < 2^62); 1: fast (q <= 2^61)
 };
-
-const rb_config* rb_find(int log_local) {
-    for (const rb_config& c : kRbConfigs)
-        if (c.log_local == log_local) return &c;
-    return nullptr;
-}
 
 template <int L, int R>
 void build_table_t(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {
@@ -374,23 +531,75 @@ void build_table_t(const regblock_layout& rb, const uint64_t* tw, const uint64_t
     }
 }
 
-template <int L, int R, int PPB, bool STAGE_OUT>
+template <int L, int R, int PPB, bool STAGE_OUT, int MINW>
 hipError_t launch_rb_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     const uint64_t frames_x = fl.batch << pv.rb.log_split;
     const size_t lds = (size_t)G::lds_elems * 8 * PPB;
     dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
-    hipLaunchKernelGGL((fwd_regblock<L, R, PPB, STAGE_OUT>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts, pv.tw_rb,
+    hipLaunchKernelGGL((fwd_regblock<L, R, PPB, STAGE_OUT, MINW>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts, pv.tw_rb,
                        pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride);
     return hipGetLastError();
 }
 
-constexpr bool kStageOut = false;
-
-template <typename F>
-hipError_t set_lds_attr(F* fn, size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+template <int L, int R, int PPB, bool STAGE_OUT, int MINW>
+hipError_t init_rb_t() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_regblock<L, R, PPB, STAGE_OUT, MINW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)rb_geom<L, R>::lds_elems * 8 * PPB));
 }
+
+template <int L, int R, int PPB, int ARITH, int MINW>
+hipError_t launch_rb2_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    const uint64_t frames_x = fl.batch << pv.rb.log_split;
+    const size_t lds = ((size_t)8 << L) * PPB;
+    dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
+    hipLaunchKernelGGL((fwd_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts, pv.tw_rb,
+                       pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
+template <int L, int R, int PPB, int ARITH, int MINW>
+hipError_t init_rb2_t() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2<L, R, PPB, ARITH, MINW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)8 << L) * PPB));
+}
+
+template <int L, int R, int PPB, int ARITH, int MINW>
+constexpr rb_entry make_entry2(int id) {
+    return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, ((size_t)8 << L) * PPB,
+                    &build_table_t<L, R>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>, ARITH};
+}
+
+template <int L, int R, int PPB, bool STAGE_OUT, int MINW>
+constexpr rb_entry make_entry(int id) {
+    return rb_entry{id, L, R, PPB, STAGE_OUT, MINW, (uint32_t)rb_geom<L, R>::table_pairs, (size_t)rb_geom<L, R>::lds_elems * 8 * PPB,
+                    &build_table_t<L, R>, &launch_rb_t<L, R, PPB, STAGE_OUT, MINW>, &init_rb_t<L, R, PPB, STAGE_OUT, MINW>, 0};
+}
+
+const rb_entry kRbEntries[] = {
+    make_entry<10, 4, 4, false, 1>(0),
+    make_entry<11, 4, 2, false, 1>(1),
+    make_entry<12, 4, 1, false, 1>(2),
+    make_entry<13, 5, 1, false, 1>(3),
+    make_entry<14, 5, 1, false, 1>(4),
+    // experiments at n = 4096
+    make_entry<12, 4, 1, true, 1>(5),
+    make_entry<12, 3, 1, false, 1>(6),
+    make_entry<12, 3, 1, false, 8>(7),
+    make_entry<12, 3, 1, true, 8>(8),
+    make_entry<12, 4, 1, false, 6>(9),
+    make_entry<12, 5, 2, false, 1>(10),
+    make_entry<12, 4, 1, false, 5>(11),
+    make_entry2<12, 3, 1, 1, 8>(12),   // fast arithmetic, 8 waves/SIMD
+    make_entry2<12, 3, 1, 0, 8>(13),   // exact arithmetic
+    make_entry2<12, 3, 1, 1, 1>(14),
+    make_entry2<12, 4, 1, 1, 1>(15),
+    make_entry2<12, 4, 1, 1, 6>(16),
+};
+constexpr int kNumRbEntries = sizeof(kRbEntries) / sizeof(kRbEntries[0]);
+
+const rb_entry* rb_lookup(int id) { return (id >= 0 && id < kNumRbEntries) ? &kRbEntries[id] : nullptr; }
 
 unsigned grid_1d(uint64_t work_items, unsigned threads) {
     uint64_t blocks = (work_items + threads - 1) / threads;
@@ -399,38 +608,41 @@ unsigned grid_1d(uint64_t work_items, unsigned threads) {
     return (unsigned)blocks;
 }
 
+template <typename F>
+hipError_t set_lds_attr(F* fn, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 }  // namespace
 
-regblock_layout regblock_choose(uint32_t n) {
+regblock_layout regblock_choose(uint32_t n, int config_id) {
     regblock_layout rb;
     int log_n = 0;
     while ((1u << log_n) < n) ++log_n;
     if (log_n < 10) return rb;  // small sizes stay on the radix-2 kernel
-    rb.log_n = log_n;
-    rb.log_split = log_n > kMaxLdsLog ? log_n - kMaxLdsLog : 0;
-    rb.log_local = log_n - rb.log_split;
-    const rb_config* c = rb_find(rb.log_local);
-    if (!c) return regblock_layout{};
-    rb.r = c->r;
-    const uint32_t nblk = 1u << rb.log_split;
-    switch (rb.log_local) {
-        case 10: rb.pairs_per_prime = rb_geom<10, 4>::table_pairs * nblk; break;
-        case 11: rb.pairs_per_prime = rb_geom<11, 4>::table_pairs * nblk; break;
-        case 12: rb.pairs_per_prime = rb_geom<12, 4>::table_pairs * nblk; break;
-        case 13: rb.pairs_per_prime = rb_geom<13, 5>::table_pairs * nblk; break;
-        case 14: rb.pairs_per_prime = rb_geom<14, 5>::table_pairs * nblk; break;
+    const int log_split = log_n > kMaxLdsLog ? log_n - kMaxLdsLog : 0;
+    const int log_local = log_n - log_split;
+    const rb_entry* e = nullptr;
+    if (config_id >= 0) {
+        e = rb_lookup(config_id);
+        if (e && e->log_local != log_local) e = nullptr;
+    } else {
+        for (const rb_entry& c : kRbEntries)
+            if (c.log_local == log_local) { e = &c; break; }
     }
+    if (!e) return rb;
+    rb.config_id = e->id;
+    rb.log_n = log_n;
+    rb.log_split = log_split;
+    rb.log_local = log_local;
+    rb.r = e->r;
+    rb.pairs_per_prime = e->table_pairs << log_split;
     return rb;
 }
 
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {
-    switch (rb.log_local) {
-        case 10: build_table_t<10, 4>(rb, tw, pre, out); break;
-        case 11: build_table_t<11, 4>(rb, tw, pre, out); break;
-        case 12: build_table_t<12, 4>(rb, tw, pre, out); break;
-        case 13: build_table_t<13, 5>(rb, tw, pre, out); break;
-        case 14: build_table_t<14, 5>(rb, tw, pre, out); break;
-    }
+    const rb_entry* e = rb_lookup(rb.config_id);
+    if (e) e->build(rb, tw, pre, out);
 }
 
 hipError_t kernels_init() {
@@ -438,11 +650,8 @@ hipError_t kernels_init() {
     const size_t big = (size_t)8 << kMaxLdsLog;
     if ((e = set_lds_attr(fwd_radix2_lds, big)) != hipSuccess) return e;
     if ((e = set_lds_attr(inv_radix2_lds, big)) != hipSuccess) return e;
-    if ((e = set_lds_attr(fwd_regblock<10, 4, 4, kStageOut>, (size_t)rb_geom<10, 4>::lds_elems * 8 * 4)) != hipSuccess) return e;
-    if ((e = set_lds_attr(fwd_regblock<11, 4, 2, kStageOut>, (size_t)rb_geom<11, 4>::lds_elems * 8 * 2)) != hipSuccess) return e;
-    if ((e = set_lds_attr(fwd_regblock<12, 4, 1, kStageOut>, (size_t)rb_geom<12, 4>::lds_elems * 8)) != hipSuccess) return e;
-    if ((e = set_lds_attr(fwd_regblock<13, 5, 1, kStageOut>, (size_t)rb_geom<13, 5>::lds_elems * 8)) != hipSuccess) return e;
-    if ((e = set_lds_attr(fwd_regblock<14, 5, 1, kStageOut>, (size_t)rb_geom<14, 5>::lds_elems * 8)) != hipSuccess) return e;
+    for (const rb_entry& c : kRbEntries)
+        if ((e = c.init()) != hipSuccess) return e;
     return hipSuccess;
 }
 
@@ -492,13 +701,8 @@ hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint
                            fl.prime_stride, fl.poly_stride);
         src = out;
     }
-    switch (pv.rb.log_local) {
-        case 10: return launch_rb_t<10, 4, 4, kStageOut>(pv, src, out, fl, s);
-        case 11: return launch_rb_t<11, 4, 2, kStageOut>(pv, src, out, fl, s);
-        case 12: return launch_rb_t<12, 4, 1, kStageOut>(pv, src, out, fl, s);
-        case 13: return launch_rb_t<13, 5, 1, kStageOut>(pv, src, out, fl, s);
-        case 14: return launch_rb_t<14, 5, 1, kStageOut>(pv, src, out, fl, s);
-    }
+    const rb_entry* e = rb_lookup(pv.rb.config_id);
+    if (e) return e->launch(pv, src, out, fl, s);
     return hipErrorInvalidValue;
 }
 

@@ -21,6 +21,7 @@ struct regblock_layout {
     int log_local = 0;   // sub-transform handled by one workgroup (log_n - log_split)
     int log_split = 0;   // leading stages done by the global split kernel
     int r = 0;           // log2 coefficients per thread
+    int config_id = -1;  // entry of the kernel registry in ntt_kernels.hip
     uint32_t pairs_per_prime = 0;  // table length per prime, in {w,w'} pairs
     bool valid() const { return r > 0; }
 };
@@ -42,7 +43,7 @@ struct frame_layout {
 
 // host-side construction of the register-blocked forward table for one prime from its
 // natural-index tables; appends rb.pairs_per_prime pairs to `out`
-regblock_layout regblock_choose(uint32_t n);
+regblock_layout regblock_choose(uint32_t n, int config_id = -1);  // -1: tuned default for n
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out);
 
 hipError_t kernels_init();  // one-time function attributes (large dynamic LDS)

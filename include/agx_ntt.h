@@ -47,7 +47,8 @@ typedef enum agx_status {
 /* kernel variants (agx_ntt_plan_set_variant); AUTO picks the tuned kernel for n */
 #define AGX_VARIANT_AUTO 0
 #define AGX_VARIANT_LDS_RADIX2 1 /* one stage per barrier, LDS resident: mirrors the reference's op sequence */
-#define AGX_VARIANT_REGBLOCK 2   /* register-blocked radix-2^R passes */
+#define AGX_VARIANT_REGBLOCK 2   /* register-blocked radix-2^R passes, tuned configuration for n */
+#define AGX_VARIANT_REGBLOCK_BASE 256 /* + k: k-th entry of the kernel registry (A/B measurements only) */
 
 const char* agx_ntt_strerror(int status);
 int agx_ntt_last_hip_error(void);     /* hipError_t of the last AGX_ERR_HIP on this thread */

@@ -12,9 +12,9 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
-enum Op { ADD32, MAD64, MAD64_SGPR, MULLO, MULHI, MAD24, MULHI24, LSHLADD64, ADDC_PAIR, CMP_CND64, FMA64, DPP_MOV, PERMSWAP, BPERMUTE, SUB_PAIR, NOPS };
+enum Op { ADD32, MAD64, MAD64_SGPR, MULLO, MULHI, MAD24, MULHI24, LSHLADD64, ADDC_PAIR, CMP_CND64, FMA64, DPP_MOV, PERMSWAP, BPERMUTE, SUB_PAIR, MUL24_E32, ADD32_E64, ADD3, CNDMASK_E32, CMP64_ONLY, CMP32_ONLY, XOR_E32, MOV_E32, LSHL_ADD_U32, NOPS };
 static const char* op_name[] = {"v_add_u32", "v_mad_u64_u32", "v_mad_u64_u32(sgpr src)", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
-    "v_lshl_add_u64", "v_add_co+v_addc_co (pair)", "v_cmp_ge_u64+2cndmask (triple)", "v_fma_f64", "v_mov_b32 dpp quad_perm", "v_permlane32_swap", "ds_bpermute_b32", "v_sub_co+v_subb_co (pair)"};
+    "v_lshl_add_u64", "v_add_co+v_addc_co (pair)", "v_cmp_ge_u64+2cndmask (triple)", "v_fma_f64", "v_mov_b32 dpp quad_perm", "v_permlane32_swap", "ds_bpermute_b32", "v_sub_co+v_subb_co (pair)", "v_mul_u32_u24_e32 (VOP2)", "v_add_u32_e64 (VOP3)", "v_add3_u32", "v_cndmask_b32_e32 (vcc)", "v_cmp_ge_u64 only", "v_cmp_lt_i32 only", "v_xor_b32_e32", "v_mov_b32_e32", "v_lshl_add_u32"};
 
 // 8 independent chains per asm block, 2 blocks per loop iteration = 16 "units" per iteration
 template <int OP>
@@ -95,6 +95,42 @@ __global__ void __launch_bounds__(256) alu_kernel(uint64_t* out, int iters, uint
                 asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n"
                              "ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)\n"
                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(addr));
+            } else if constexpr (OP == MUL24_E32) {
+                asm volatile("v_mul_u32_u24_e32 %0, %0, %8\n v_mul_u32_u24_e32 %1, %1, %8\n v_mul_u32_u24_e32 %2, %2, %8\n v_mul_u32_u24_e32 %3, %3, %8\n"
+                             "v_mul_u32_u24_e32 %4, %4, %8\n v_mul_u32_u24_e32 %5, %5, %8\n v_mul_u32_u24_e32 %6, %6, %8\n v_mul_u32_u24_e32 %7, %7, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+            } else if constexpr (OP == ADD32_E64) {
+                asm volatile("v_add_u32_e64 %0, %0, %8\n v_add_u32_e64 %1, %1, %8\n v_add_u32_e64 %2, %2, %8\n v_add_u32_e64 %3, %3, %8\n"
+                             "v_add_u32_e64 %4, %4, %8\n v_add_u32_e64 %5, %5, %8\n v_add_u32_e64 %6, %6, %8\n v_add_u32_e64 %7, %7, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+            } else if constexpr (OP == ADD3) {
+                asm volatile("v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n"
+                             "v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b), "v"(a));
+            } else if constexpr (OP == CNDMASK_E32) {
+                asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n"
+                             "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b) : "vcc");
+            } else if constexpr (OP == CMP64_ONLY) {
+                asm volatile("v_cmp_ge_u64 vcc, %0, %1\n v_cmp_ge_u64 vcc, %2, %3\n v_cmp_ge_u64 vcc, %4, %5\n v_cmp_ge_u64 vcc, %6, %7\n"
+                             "v_cmp_ge_u64 vcc, %1, %2\n v_cmp_ge_u64 vcc, %3, %4\n v_cmp_ge_u64 vcc, %5, %6\n v_cmp_ge_u64 vcc, %7, %0\n"
+                             :: "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(c4), "v"(c5), "v"(c6), "v"(c7) : "vcc");
+            } else if constexpr (OP == CMP32_ONLY) {
+                asm volatile("v_cmp_lt_i32 vcc, %0, %1\n v_cmp_lt_i32 vcc, %2, %3\n v_cmp_lt_i32 vcc, %4, %5\n v_cmp_lt_i32 vcc, %6, %7\n"
+                             "v_cmp_lt_i32 vcc, %1, %2\n v_cmp_lt_i32 vcc, %3, %4\n v_cmp_lt_i32 vcc, %5, %6\n v_cmp_lt_i32 vcc, %7, %0\n"
+                             :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7) : "vcc");
+            } else if constexpr (OP == XOR_E32) {
+                asm volatile("v_xor_b32_e32 %0, %0, %8\n v_xor_b32_e32 %1, %1, %8\n v_xor_b32_e32 %2, %2, %8\n v_xor_b32_e32 %3, %3, %8\n"
+                             "v_xor_b32_e32 %4, %4, %8\n v_xor_b32_e32 %5, %5, %8\n v_xor_b32_e32 %6, %6, %8\n v_xor_b32_e32 %7, %7, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+            } else if constexpr (OP == MOV_E32) {
+                asm volatile("v_mov_b32_e32 %0, %1\n v_mov_b32_e32 %1, %2\n v_mov_b32_e32 %2, %3\n v_mov_b32_e32 %3, %4\n"
+                             "v_mov_b32_e32 %4, %5\n v_mov_b32_e32 %5, %6\n v_mov_b32_e32 %6, %7\n v_mov_b32_e32 %7, %0\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            } else if constexpr (OP == LSHL_ADD_U32) {
+                asm volatile("v_lshl_add_u32 %0, %0, 1, %8\n v_lshl_add_u32 %1, %1, 1, %8\n v_lshl_add_u32 %2, %2, 1, %8\n v_lshl_add_u32 %3, %3, 1, %8\n"
+                             "v_lshl_add_u32 %4, %4, 1, %8\n v_lshl_add_u32 %5, %5, 1, %8\n v_lshl_add_u32 %6, %6, 1, %8\n v_lshl_add_u32 %7, %7, 1, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
             }
         }
     }
@@ -195,12 +231,13 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  clock=%d kHz  L2=%d  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate, prop.l2CacheSize, prop.sharedMemPerBlock);
     if (do_alu) {
-        uint64_t* d_out; CK(hipMalloc(&d_out, 256 * 8 * 4 * 8));
+        uint64_t* d_out; CK(hipMalloc(&d_out, 256 * 8 * 4 * 8 * 2));
         printf("ALU issue cost (16 independent chains per loop body; lower = faster)\n");
-        for (int w : {1, 2, 4}) {
+        for (int w : {1, 2, 4, 8}) {
             run_alu<ADD32>(d_out, w); run_alu<MAD64>(d_out, w); run_alu<MAD64_SGPR>(d_out, w); run_alu<MULLO>(d_out, w); run_alu<MULHI>(d_out, w);
             run_alu<MAD24>(d_out, w); run_alu<MULHI24>(d_out, w); run_alu<LSHLADD64>(d_out, w); run_alu<ADDC_PAIR>(d_out, w); run_alu<SUB_PAIR>(d_out, w);
             run_alu<CMP_CND64>(d_out, w); run_alu<FMA64>(d_out, w); run_alu<DPP_MOV>(d_out, w); run_alu<PERMSWAP>(d_out, w); run_alu<BPERMUTE>(d_out, w);
+            run_alu<MUL24_E32>(d_out, w); run_alu<ADD32_E64>(d_out, w); run_alu<ADD3>(d_out, w); run_alu<CNDMASK_E32>(d_out, w); run_alu<CMP64_ONLY>(d_out, w); run_alu<CMP32_ONLY>(d_out, w); run_alu<XOR_E32>(d_out, w); run_alu<MOV_E32>(d_out, w); run_alu<LSHL_ADD_U32>(d_out, w);
             printf("\n");
         }
         CK(hipFree(d_out));

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""tools/sweep.py -- A/B the registered kernel configurations on the roofline workload
+(n=4096, 4 primes, batch 4096; 4 rotating slabs), all in ONE process, interleaved rounds
+(cdna_hip_programming.md rule 24).  Every configuration's output is compared bit for bit with
+the radix-2 kernel's before it is timed.  Usage: python tools/sweep.py [ids...]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import agilex_ntt_amd as agx  # noqa: E402
+
+N, P, B, SLABS = 4096, 4, 4096, 4
+ids = [int(a) for a in sys.argv[1:]] or [2, 5, 6, 7, 8, 9, 10, 11]
+qs = agx.find_primes(60, N, P)
+plan = agx.Plan(N, qs)
+stream = torch.cuda.current_stream().cuda_stream
+per = P * B * N
+slabs = [torch.empty(per, dtype=torch.int64, device="cuda") for _ in range(SLABS)]
+for i, s in enumerate(slabs):
+    plan.fill_synthetic(s.data_ptr(), B, i * B, 42, stream)
+ref_in = slabs[0].clone()
+ref = torch.empty_like(ref_in)
+plan.set_variant(agx.VARIANT_LDS_RADIX2)
+plan.forward(ref_in.data_ptr(), ref.data_ptr(), B, stream)
+torch.cuda.synchronize()
+out = torch.empty_like(ref_in)
+ok = {}
+for k in ids:
+    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + k)
+    out.zero_()
+    plan.forward(ref_in.data_ptr(), out.data_ptr(), B, stream)
+    torch.cuda.synchronize()
+    ok[k] = bool(torch.equal(out, ref))
+times = {k: [] for k in ids}
+for rnd in range(5):
+    for k in ids:
+        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + k)
+        for i in range(3):
+            plan.forward(slabs[i % SLABS].data_ptr(), slabs[i % SLABS].data_ptr(), B, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(20):
+            s = slabs[i % SLABS]
+            plan.forward(s.data_ptr(), s.data_ptr(), B, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        times[k].append(e0.elapsed_time(e1) / 20)
+print(f"{'id':>3} {'bit-exact':>9} {'min ms':>8} {'med ms':>8} {'MNTT/s':>8} {'GB/s':>8} {'%8TB/s':>7}")
+for k in ids:
+    t = sorted(times[k])
+    mn, md = t[0], t[len(t) // 2]
+    rate = P * B / (md * 1e-3)
+    print(f"{k:>3} {str(ok[k]):>9} {mn:8.4f} {md:8.4f} {rate / 1e6:8.2f} {rate * 16 * N / 1e9:8.1f} {rate * 16 * N / 8e12 * 100:7.2f}")
