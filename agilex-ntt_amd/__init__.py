@@ -234,11 +234,5 @@ class Plan:
             pass
 
 
-# ---------------------------------------------------------------------------------------
-# sharding of independent frames over ranks (no collective on the data path)
-# ---------------------------------------------------------------------------------------
-def shard_range(total, rank, world):
-    """Contiguous block [lo, hi) of `total` polynomials owned by `rank` of `world`."""
-    lo = total * rank // world
-    hi = total * (rank + 1) // world
-    return lo, hi
+# sharding of independent frames over ranks lives in distributed.py (no collective on the data path)
+from .distributed import Group, aggregate_throughput, shard_range  # noqa: E402,F401

@@ -169,12 +169,33 @@ __device__ __forceinline__ void ct_butterfly_fast(uint64_t& x, uint64_t& y, uint
     x = xn;
 }
 
-// [0,2m) -> [0,q) at the last stage (m = 2q: two steps; m = 4q: three)
+// [0,2m) -> [0,q) at the last stage (m = 2q: two steps; m = 4q: three).  The fast form may use
+// the sign trick for every step (all values < 2^63 after the first one); the exact form must
+// compare (q may exceed 2^61).
+__device__ __forceinline__ uint64_t csub_sign_c(uint64_t x, uint64_t m, uint64_t nm) {
+    const uint64_t d = x + nm;
+    const uint32_t neg = (uint32_t)((int32_t)(uint32_t)(d >> 32) >> 31);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 add;
+    add.x = neg & (uint32_t)m;
+    add.y = neg & (uint32_t)(m >> 32);
+    return d + __builtin_bit_cast(uint64_t, add);
+}
+
+struct final_consts {   // fast form only
+    uint64_t q2, nq2, q1, nq1;
+};
+
 template <bool FAST>
-__device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k) {
-    if constexpr (FAST) v = csub(v, k.m);
-    v = csub(v, k.q << 1);
-    return csub(v, k.q);
+__device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k, const final_consts& f) {
+    if constexpr (FAST) {
+        v = csub_sign(v, k);                 // [0,8q) -> [0,4q)
+        v = csub_sign_c(v, f.q2, f.nq2);     // -> [0,2q)
+        return csub_sign_c(v, f.q1, f.nq1);  // -> [0,q)
+    } else {
+        v = csub(v, k.q << 1);
+        return csub(v, k.q);
+    }
 }
 
 }  // namespace agx

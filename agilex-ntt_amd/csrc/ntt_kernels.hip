@@ -378,6 +378,11 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     k.nm = opaque_sgpr64(0 - k.m);
     k.one_a = opaque_one<0>();
     k.one_b = opaque_one<1>();
+    final_consts fc;
+    fc.q2 = k.q << 1;
+    fc.nq2 = opaque_sgpr64(0 - fc.q2);
+    fc.q1 = k.q;
+    fc.nq1 = opaque_sgpr64(0 - fc.q1);
     const twpair* tbl = tw_rb + (size_t)prime * pairs_per_prime;
     const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)blk << L);
     uint64_t* slab = lds + ((size_t)slot << L);
@@ -392,13 +397,24 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
         constexpr bool uniform = rlo >= 6;    // tid >> rlo is the same for the 64 lanes of a wave
         const uint32_t low = tid & ((1u << rlo) - 1u), high = tid >> rlo;
         const uint32_t sbase = lds_swz(low | (high << (rlo + R)));
+        // this pass's 2^R - 1 table entries, fetched before the coefficients are needed
+        twpair tw[C];
+        if constexpr (uniform) {
+            const uint32_t hcol = (uint32_t)__builtin_amdgcn_readfirstlane((int)high);
+            const twpair* col = tbl + G::table_off(p) * (1u << split_log) + ((size_t)blk * H + hcol) * C;
+#pragma unroll
+            for (int j = 1; j < C; ++j) tw[j] = load_uniform(col + j);      // merged into wide s_loads
+        } else {
+            const twpair* col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + high;
+            const uint32_t hstride = (uint32_t)H << split_log;
+#pragma unroll
+            for (int j = 1; j < C; ++j)
+                if (j >= (1 << (R - 1 - (hi - rlo)))) tw[j] = col[(size_t)j * hstride];
+        }
         if constexpr (p > 0) {
 #pragma unroll
             for (int r = 0; r < C; ++r) x[r] = slab[sbase ^ lds_swz((uint32_t)r << rlo)];
         }
-        const uint32_t hcol = uniform ? (uint32_t)__builtin_amdgcn_readfirstlane((int)high) : high;
-        const twpair* col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + (H == 1 ? 0u : hcol);
-        const uint32_t hstride = (uint32_t)H << split_log;
         static_for<0, hi - rlo + 1>([&](auto S) {
             constexpr int rb = (hi - rlo) - S;
             constexpr int kk = R - 1 - rb;
@@ -408,26 +424,20 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                 if ((r0 >> rb) & 1) continue;
                 const int r1 = r0 | (1 << rb);
                 const int j = (1 << kk) + (r0 >> (rb + 1));
-                twpair w;
-                if constexpr (uniform) w = load_uniform(col + (size_t)j * hstride);   // s_load_dwordx4
-                else w = col[(size_t)j * hstride];
-                if constexpr (FAST) ct_butterfly_fast(x[r0], x[r1], w.x, w.y, k);
-                else ct_butterfly_exact(x[r0], x[r1], w.x, w.y, k);
+                if constexpr (FAST) ct_butterfly_fast(x[r0], x[r1], tw[j].x, tw[j].y, k);
+                else ct_butterfly_exact(x[r0], x[r1], tw[j].x, tw[j].y, k);
                 if constexpr (last_stage) {
-                    x[r0] = reduce_final<FAST>(x[r0], k);
-                    x[r1] = reduce_final<FAST>(x[r1], k);
+                    x[r0] = reduce_final<FAST>(x[r0], k, fc);
+                    x[r1] = reduce_final<FAST>(x[r1], k, fc);
                 }
             }
         });
         if constexpr (p < NP - 1) {
-            constexpr bool local_next = G::exchange_is_wave_local(p);
-            constexpr bool local_prev = p > 0 && G::exchange_is_wave_local(p - 1);
-            // the slab region this thread overwrites was last read in this pass: by this wave only
-            // if the previous exchange was wave-local, by any wave otherwise
-            if constexpr (p > 0 && !local_prev) __syncthreads();
+            // A thread overwrites exactly the image words it read for this pass, so no other
+            // thread can still need them: only the read side of an exchange has to be ordered.
 #pragma unroll
             for (int r = 0; r < C; ++r) slab[sbase ^ lds_swz((uint32_t)r << rlo)] = x[r];
-            if constexpr (!local_next) __syncthreads();
+            if constexpr (!G::exchange_is_wave_local(p)) __syncthreads();
             else __builtin_amdgcn_wave_barrier();
         }
     });
@@ -435,8 +445,6 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     // last pass: rlo = 0, thread holds coefficients [tid*C, tid*C + C); a wave holds 64*C
     // contiguous ones.  Through the image once more so that global stores are lane-contiguous.
     static_assert(G::last_pass_wave_contiguous(), "store path assumes a wave-contiguous last pass");
-    constexpr bool prev_local = NP > 1 && G::exchange_is_wave_local(NP - 2);
-    if constexpr (NP > 1 && !prev_local) __syncthreads();
 #pragma unroll
     for (int r = 0; r < C; ++r) slab[lds_swz((tid << R) | (uint32_t)r)] = x[r];
     __builtin_amdgcn_wave_barrier();
@@ -507,7 +515,7 @@ struct rb_entry {
     int arith;   // 0: exact (reference op sequence, q < 2^62); 1: fast (q <= 2^61)
 };
 
-template <int L, int R>
+template <int L, int R, bool col_major = false>
 void build_table_t(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {
     using G = rb_geom<L, R>;
     const uint32_t nblk = 1u << rb.log_split;
@@ -525,7 +533,11 @@ void build_table_t(const regblock_layout& rb, const uint64_t* tw, const uint64_t
             for (uint32_t blk = 0; blk < nblk; ++blk)
                 for (int h = 0; h < H; ++h) {
                     const uint32_t idx = (m_local << rb.log_split) + blk * m_local + ((uint32_t)h << k) + (uint32_t)o;
-                    t[(size_t)j * H * nblk + (size_t)blk * H + h] = make_ulonglong2(tw[idx], pre[idx]);
+                    const size_t col = (size_t)blk * H + h;
+                    // wave-uniform passes keep one column's C entries contiguous (wide scalar loads);
+                    // per-lane passes keep one entry's columns contiguous (coalesced vector loads)
+                    const size_t at = (col_major && rlo >= 6) ? col * G::C + j : (size_t)j * H * nblk + col;
+                    t[at] = make_ulonglong2(tw[idx], pre[idx]);
                 }
         }
     }
@@ -568,7 +580,7 @@ hipError_t init_rb2_t() {
 template <int L, int R, int PPB, int ARITH, int MINW>
 constexpr rb_entry make_entry2(int id) {
     return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, ((size_t)8 << L) * PPB,
-                    &build_table_t<L, R>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>, ARITH};
+                    &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>, ARITH};
 }
 
 template <int L, int R, int PPB, bool STAGE_OUT, int MINW>
@@ -615,7 +627,7 @@ hipError_t set_lds_attr(F* fn, size_t bytes) {
 
 }  // namespace
 
-regblock_layout regblock_choose(uint32_t n, int config_id) {
+regblock_layout regblock_choose(uint32_t n, int config_id, bool allow_fast) {
     regblock_layout rb;
     int log_n = 0;
     while ((1u << log_n) < n) ++log_n;
@@ -625,10 +637,14 @@ regblock_layout regblock_choose(uint32_t n, int config_id) {
     const rb_entry* e = nullptr;
     if (config_id >= 0) {
         e = rb_lookup(config_id);
-        if (e && e->log_local != log_local) e = nullptr;
+        if (e && (e->log_local != log_local || (e->arith == 1 && !allow_fast))) e = nullptr;
     } else {
-        for (const rb_entry& c : kRbEntries)
-            if (c.log_local == log_local) { e = &c; break; }
+        // tuned defaults, best first; fast arithmetic only when every modulus is <= 2^61
+        static const int kDefaults[] = {12, 13, 0, 1, 2, 3, 4};
+        for (int id : kDefaults) {
+            const rb_entry* c = rb_lookup(id);
+            if (c && c->log_local == log_local && (c->arith == 0 || allow_fast)) { e = c; break; }
+        }
     }
     if (!e) return rb;
     rb.config_id = e->id;

@@ -33,37 +33,47 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_NTT = 16 * N_COEFF         # read 8n + write 8n
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
 def cpu_baseline(target_seconds=12.0):
     """The CPU restatement of the reference butterfly (oracle, kind "port") timed on this
-    box's host cores on a bounded sample of the same workload shape (n=4096, 60-bit q)."""
-    import numpy as np
-
+    box's host cores on a bounded sample of the same workload shape (n=4096, 60-bit q):
+    repeated passes over a fixed 1024-frames-per-thread buffer until ~target_seconds."""
     from oracle import oracle
 
-    cores = len(os.sched_getaffinity(0))
+    cores = int(os.environ.get("AGX_BENCH_CPU_THREADS", "0")) or host_cores()
     q = oracle.find_prime(PRIME_BITS, N_COEFF)
     psi = oracle.min_root(q, N_COEFF)
     tw, pre = oracle.make_tables(q, psi, N_COEFF)
-    calib = 64 * cores
-    x = oracle.fill_splitmix(calib * N_COEFF, 42, q)
+    frames = 1024 * cores
+    x = oracle.fill_splitmix(frames * N_COEFF, 42, q)
     t0 = time.perf_counter()
-    oracle.forward_mt(x, q, tw, pre, N_COEFF, cores)
-    rate = calib / (time.perf_counter() - t0)
-    frames = max(calib, int(rate * target_seconds) // cores * cores)
-    frames = min(frames, (8 << 30) // (8 * N_COEFF) // 2)  # at most 4 GiB of input
-    x = oracle.fill_splitmix(frames * N_COEFF, 43, q)
-    best = None
+    oracle.forward_mt(x, q, tw, pre, N_COEFF, cores)      # also the warm-up pass
+    first = time.perf_counter() - t0
+    passes = max(1, min(64, int(target_seconds / max(first, 1e-3))))
     t0 = time.perf_counter()
-    oracle.forward_mt(x, q, tw, pre, N_COEFF, cores)
-    best = time.perf_counter() - t0
+    for _ in range(passes):
+        oracle.forward_mt(x, q, tw, pre, N_COEFF, cores)
+    elapsed = time.perf_counter() - t0
+    one = x[: N_COEFF * 1024]
     t0 = time.perf_counter()
-    oracle.forward_mt(x[: N_COEFF * max(1, frames // cores // 8)], q, tw, pre, N_COEFF, 1)
-    single = max(1, frames // cores // 8) / (time.perf_counter() - t0)
+    oracle.forward_mt(one, q, tw, pre, N_COEFF, 1)
+    single = 1024 / (time.perf_counter() - t0)
     return {
-        "value": frames / best, "unit": "NTT/s", "cores": cores, "kind": "port",
+        "value": frames * passes / elapsed, "unit": "NTT/s", "cores": cores, "kind": "port",
         "single_core_value": single,
-        "sample": f"{frames} frames of n={N_COEFF}, one {PRIME_BITS}-bit modulus, oracle/ntt_oracle.c "
-                  f"(restatement of the reference butterfly) over {cores} pthreads, {best:.1f} s",
+        "sample": f"{passes} passes over {frames} frames of n={N_COEFF}, one {PRIME_BITS}-bit modulus, "
+                  f"oracle/ntt_oracle.c (restatement of the reference butterfly) on {cores} pthreads, {elapsed:.1f} s",
     }
 
 
@@ -80,19 +90,15 @@ def main():
 
     import agilex_ntt_amd as agx
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch N>1 through torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    grp = agx.Group(backend="nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+    rank, world = grp.rank, grp.world
 
     batch = args.batch
     qs = agx.find_primes(PRIME_BITS, N_COEFF, NUM_PRIMES)
@@ -120,8 +126,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    grp.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -130,18 +135,14 @@ def main():
         step(args.warmup + i)
     ev1.record()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    grp.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration over the timed region
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = grp.max_over_ranks(elapsed)
 
     ntts_per_step_per_gpu = NUM_PRIMES * batch
-    value = world * ntts_per_step_per_gpu * args.steps / elapsed
+    value = agx.aggregate_throughput(ntts_per_step_per_gpu, args.steps, world, elapsed)
     achieved = ntts_per_step_per_gpu * ALGO_BYTES_PER_NTT / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -173,8 +174,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     plan.close()
-    if dist:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -142,6 +142,45 @@ def test_structured_known_answers(agx, dev, n):
     plan.close()
 
 
+@pytest.mark.parametrize("bits", [30, 60, 61, 62])
+@pytest.mark.parametrize("config", ["default", 2, 12, 13])
+def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
+    """every registered n=4096 kernel (first-generation exact, second-generation fast / exact)
+    against the oracle, for 30-, 60-, 61- and 62-bit moduli; 62-bit moduli must be refused by the
+    fast kernel and run on the exact one by default"""
+    n, batch, primes = 4096, 3, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes, inverse=False)
+    if config != "default":
+        if config == 12 and bits == 62:
+            with pytest.raises(agx.AgxError) as ei:
+                plan.set_variant(agx.VARIANT_REGBLOCK_BASE + 12)
+            assert ei.value.status == 2
+            plan.close()
+            return
+        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+    rng = np.random.default_rng(bits * 100 + (config if config != "default" else 7))
+    x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4 if bits < 62 else 3) for t in tabs])
+    d = dev.to_device(x)
+    plan.forward(d.data_ptr(), d.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d), _oracle_forward_rns(orc, x, tabs, n, batch))
+    plan.close()
+
+
+def test_extreme_coefficients_fast_kernel(agx, orc, dev):
+    """worst-case lazy ranges: all coefficients 4q-1 / q-1 / 0 under the largest 61-bit modulus"""
+    n = 4096
+    q = orc.find_prime(61, n)
+    psi = orc.min_root(q, n)
+    tw, pre = orc.make_tables(q, psi, n)
+    plan = agx.Plan(n, [q], psi=[psi])
+    x = np.concatenate([np.full(n, 4 * q - 1, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64),
+                        np.where(np.arange(n) % 2 == 0, np.uint64(4 * q - 1), np.uint64(0))])
+    d = dev.to_device(x)
+    plan.forward(d.data_ptr(), d.data_ptr(), 4, dev.stream)
+    assert np.array_equal(dev.to_host(d), orc.forward(x, q, tw, pre, n))
+    plan.close()
+
+
 @pytest.mark.parametrize("n", ALL_SIZES)
 def test_inverse_round_trip_and_oracle(agx, orc, dev, n):
     bits = 30 if n == 1024 else 60
