@@ -397,19 +397,20 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
         constexpr bool uniform = rlo >= 6;    // tid >> rlo is the same for the 64 lanes of a wave
         const uint32_t low = tid & ((1u << rlo) - 1u), high = tid >> rlo;
         const uint32_t sbase = lds_swz(low | (high << (rlo + R)));
-        // this pass's 2^R - 1 table entries, fetched before the coefficients are needed
+        // wave-uniform passes fetch their 2^R - 1 table entries up front with wide scalar loads;
+        // per-lane passes load each entry where it is used (prefetching all of them costs 28 VGPRs
+        // and spills at the 64-register budget of 8 waves/SIMD)
         twpair tw[C];
+        const twpair* col = nullptr;
+        uint32_t hstride = 0;
         if constexpr (uniform) {
             const uint32_t hcol = (uint32_t)__builtin_amdgcn_readfirstlane((int)high);
-            const twpair* col = tbl + G::table_off(p) * (1u << split_log) + ((size_t)blk * H + hcol) * C;
+            const twpair* ucol = tbl + G::table_off(p) * (1u << split_log) + ((size_t)blk * H + hcol) * C;
 #pragma unroll
-            for (int j = 1; j < C; ++j) tw[j] = load_uniform(col + j);      // merged into wide s_loads
+            for (int j = 1; j < C; ++j) tw[j] = load_uniform(ucol + j);      // merged into wide s_loads
         } else {
-            const twpair* col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + high;
-            const uint32_t hstride = (uint32_t)H << split_log;
-#pragma unroll
-            for (int j = 1; j < C; ++j)
-                if (j >= (1 << (R - 1 - (hi - rlo)))) tw[j] = col[(size_t)j * hstride];
+            col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + high;
+            hstride = (uint32_t)H << split_log;
         }
         if constexpr (p > 0) {
 #pragma unroll
@@ -424,8 +425,11 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                 if ((r0 >> rb) & 1) continue;
                 const int r1 = r0 | (1 << rb);
                 const int j = (1 << kk) + (r0 >> (rb + 1));
-                if constexpr (FAST) ct_butterfly_fast(x[r0], x[r1], tw[j].x, tw[j].y, k);
-                else ct_butterfly_exact(x[r0], x[r1], tw[j].x, tw[j].y, k);
+                twpair w;
+                if constexpr (uniform) w = tw[j];
+                else w = col[(size_t)j * hstride];
+                if constexpr (FAST) ct_butterfly_fast(x[r0], x[r1], w.x, w.y, k);
+                else ct_butterfly_exact(x[r0], x[r1], w.x, w.y, k);
                 if constexpr (last_stage) {
                     x[r0] = reduce_final<FAST>(x[r0], k, fc);
                     x[r1] = reduce_final<FAST>(x[r1], k, fc);
@@ -608,6 +612,11 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 1, 1>(14),
     make_entry2<12, 4, 1, 1, 1>(15),
     make_entry2<12, 4, 1, 1, 6>(16),
+    // second generation, other sizes (fast, exact)
+    make_entry2<10, 3, 4, 1, 8>(17), make_entry2<10, 3, 4, 0, 8>(18),
+    make_entry2<11, 3, 2, 1, 8>(19), make_entry2<11, 3, 2, 0, 8>(20),
+    make_entry2<13, 3, 1, 1, 8>(21), make_entry2<13, 3, 1, 0, 8>(22),
+    make_entry2<14, 4, 1, 1, 4>(23), make_entry2<14, 4, 1, 0, 4>(24),
 };
 constexpr int kNumRbEntries = sizeof(kRbEntries) / sizeof(kRbEntries[0]);
 
@@ -640,7 +649,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, bool allow_fast) {
         if (e && (e->log_local != log_local || (e->arith == 1 && !allow_fast))) e = nullptr;
     } else {
         // tuned defaults, best first; fast arithmetic only when every modulus is <= 2^61
-        static const int kDefaults[] = {12, 13, 0, 1, 2, 3, 4};
+        static const int kDefaults[] = {12, 13, 17, 18, 19, 20, 21, 22, 23, 24, 0, 1, 2, 3, 4};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
             if (c && c->log_local == log_local && (c->arith == 0 || allow_fast)) { e = c; break; }

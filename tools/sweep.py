@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """tools/sweep.py -- A/B the registered kernel configurations on the roofline workload
-(n=4096, 4 primes, batch 4096; 4 rotating slabs), all in ONE process, interleaved rounds
+(default n=4096, 4 primes, batch 4096; 4 rotating slabs; --n/--primes/--batch for other shapes), all in ONE process, interleaved rounds
 (cdna_hip_programming.md rule 24).  Every configuration's output is compared bit for bit with
-the radix-2 kernel's before it is timed.  Usage: python tools/sweep.py [ids...]"""
+the radix-2 kernel's before it is timed.  Usage: python tools/sweep.py [--n N --primes P --batch B] [ids...]   (id -1 = the radix-2 kernel)"""
 import os
 import sys
 
@@ -13,8 +13,17 @@ import torch  # noqa: E402
 
 import agilex_ntt_amd as agx  # noqa: E402
 
-N, P, B, SLABS = 4096, 4, 4096, 4
-ids = [int(a) for a in sys.argv[1:]] or [2, 5, 6, 7, 8, 9, 10, 11]
+import argparse  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("ids", nargs="*", type=int)
+ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--primes", type=int, default=4)
+ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--slabs", type=int, default=4)
+args = ap.parse_args()
+N, P, B, SLABS = args.n, args.primes, args.batch, args.slabs
+ids = args.ids or [2, 5, 6, 7, 8, 9, 10, 11]
 qs = agx.find_primes(60, N, P)
 plan = agx.Plan(N, qs)
 stream = torch.cuda.current_stream().cuda_stream
@@ -29,8 +38,12 @@ plan.forward(ref_in.data_ptr(), ref.data_ptr(), B, stream)
 torch.cuda.synchronize()
 out = torch.empty_like(ref_in)
 ok = {}
+def select(k):
+    plan.set_variant(agx.VARIANT_LDS_RADIX2 if k < 0 else agx.VARIANT_REGBLOCK_BASE + k)
+
+
 for k in ids:
-    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + k)
+    select(k)
     out.zero_()
     plan.forward(ref_in.data_ptr(), out.data_ptr(), B, stream)
     torch.cuda.synchronize()
@@ -38,7 +51,7 @@ for k in ids:
 times = {k: [] for k in ids}
 for rnd in range(5):
     for k in ids:
-        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + k)
+        select(k)
         for i in range(3):
             plan.forward(slabs[i % SLABS].data_ptr(), slabs[i % SLABS].data_ptr(), B, stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
