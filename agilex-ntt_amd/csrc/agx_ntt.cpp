@@ -25,6 +25,7 @@ struct agx_ntt_plan {
     ulonglong2* d_tw = nullptr;
     ulonglong2* d_itw = nullptr;
     ulonglong2* d_tw_rb = nullptr;
+    ulonglong2* d_itw_rb = nullptr;
     regblock_layout rb;
 };
 
@@ -64,6 +65,7 @@ plan_view view_of(const agx_ntt_plan* p) {
     v.itw = p->d_itw;
     v.rb = p->rb;
     v.tw_rb = p->d_tw_rb;
+    v.itw_rb = p->d_itw_rb;
     return v;
 }
 
@@ -73,6 +75,7 @@ void free_plan(agx_ntt_plan* p) {
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_itw) (void)hipFree(p->d_itw);
     if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
+    if (p->d_itw_rb) (void)hipFree(p->d_itw_rb);
     delete p;
 }
 
@@ -126,7 +129,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         }
     }
     p->rb = regblock_choose(n, -1, p->all_le_61);
-    std::vector<ulonglong2> rb_pairs;
+    std::vector<ulonglong2> rb_pairs, irb_pairs;
     for (uint32_t k = 0; k < num_primes; ++k) {
         const uint64_t q = moduli[k];
         prime_consts& c = consts[k];
@@ -146,6 +149,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
             for (uint32_t j = 0; j < n; ++j) itw_pairs[(size_t)k * n + j] = make_ulonglong2(itwk[j], iprek[j]);
             c.w1n = mul_mod(itwk[1] % q, c.n_inv, q);
             c.w1n_p = shoup_quotient(c.w1n, q);
+            if (p->rb.valid()) regblock_build_table(p->rb, itwk, iprek, irb_pairs);
         }
         if (p->rb.valid()) regblock_build_table(p->rb, twk, prek, rb_pairs);
     }
@@ -153,6 +157,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     if ((rc = upload(&p->d_tw, tw_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (itw && (rc = upload(&p->d_itw, itw_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && (rc = upload(&p->d_tw_rb, rb_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (p->rb.valid() && itw && (rc = upload(&p->d_itw_rb, irb_pairs)) != AGX_OK) { free_plan(p); return rc; }
     *out = p;
     return AGX_OK;
 }
@@ -252,19 +257,25 @@ int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant) {
         if (!rb.valid()) {
             if (variant == AGX_VARIANT_REGBLOCK) return AGX_ERR_BAD_SIZE;
         } else if (rb.config_id != plan->rb.config_id) {
-            std::vector<ulonglong2> tw((size_t)plan->num_primes * plan->n), rb_pairs;
-            AGX_HIP(hipMemcpy(tw.data(), plan->d_tw, tw.size() * sizeof(ulonglong2), hipMemcpyDeviceToHost));
             std::vector<uint64_t> w(plan->n), wp(plan->n);
-            for (uint32_t k = 0; k < plan->num_primes; ++k) {
-                for (uint32_t j = 0; j < plan->n; ++j) { w[j] = tw[(size_t)k * plan->n + j].x; wp[j] = tw[(size_t)k * plan->n + j].y; }
-                regblock_build_table(rb, w.data(), wp.data(), rb_pairs);
+            ulonglong2* d_new[2] = {nullptr, nullptr};
+            const ulonglong2* d_src[2] = {plan->d_tw, plan->d_itw};
+            for (int which = 0; which < 2; ++which) {
+                if (!d_src[which]) continue;
+                std::vector<ulonglong2> tw((size_t)plan->num_primes * plan->n), rb_pairs;
+                AGX_HIP(hipMemcpy(tw.data(), d_src[which], tw.size() * sizeof(ulonglong2), hipMemcpyDeviceToHost));
+                for (uint32_t k = 0; k < plan->num_primes; ++k) {
+                    for (uint32_t j = 0; j < plan->n; ++j) { w[j] = tw[(size_t)k * plan->n + j].x; wp[j] = tw[(size_t)k * plan->n + j].y; }
+                    regblock_build_table(rb, w.data(), wp.data(), rb_pairs);
+                }
+                int rc = upload(&d_new[which], rb_pairs);
+                if (rc != AGX_OK) return rc;
             }
-            ulonglong2* d_new = nullptr;
-            int rc = upload(&d_new, rb_pairs);
-            if (rc != AGX_OK) return rc;
             AGX_HIP(hipDeviceSynchronize());
             if (plan->d_tw_rb) (void)hipFree(plan->d_tw_rb);
-            plan->d_tw_rb = d_new;
+            if (plan->d_itw_rb) (void)hipFree(plan->d_itw_rb);
+            plan->d_tw_rb = d_new[0];
+            plan->d_itw_rb = d_new[1];
             plan->rb = rb;
         }
     }
@@ -308,7 +319,10 @@ int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint
     if (!plan->has_inverse) return AGX_ERR_NO_INVERSE;
     if (batch == 0) return AGX_OK;
     const frame_layout fl{batch, prime_stride, poly_stride};
-    AGX_HIP(launch_inverse_radix2(view_of(plan), d_in, d_out, fl, static_cast<hipStream_t>(stream)));
+    const plan_view pv = view_of(plan);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool fast_path = use_regblock(plan) && regblock_has_inverse(plan->rb) && plan->d_itw_rb;
+    AGX_HIP(fast_path ? launch_inverse_regblock(pv, d_in, d_out, fl, s) : launch_inverse_radix2(pv, d_in, d_out, fl, s));
     return AGX_OK;
 }
 
@@ -331,9 +345,18 @@ int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint6
 
 int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                     uint64_t* d_scratch, uint64_t batch, void* stream) {
-    if (!plan || !d_a || !d_b || !d_c || !d_scratch) return AGX_ERR_NULL_POINTER;
-    if (d_scratch == d_a || d_scratch == d_b || d_scratch == d_c) return AGX_ERR_BAD_ARGUMENT;
+    if (!plan || !d_a || !d_b || !d_c) return AGX_ERR_NULL_POINTER;
     if (!plan->has_inverse) return AGX_ERR_NO_INVERSE;
+    if (batch == 0) return AGX_OK;
+    if (use_regblock(plan) && regblock_has_polymul(plan->rb) && plan->d_itw_rb) {
+        // one kernel: both forward transforms, the product and the inverse stay on chip (24n bytes of HBM traffic);
+        // every workgroup reads its a and b frames completely before it writes c, so c may alias either
+        const frame_layout fl{batch, (int64_t)(batch * plan->n), (int64_t)plan->n};
+        AGX_HIP(launch_polymul_regblock(view_of(plan), d_a, d_b, d_c, fl, static_cast<hipStream_t>(stream)));
+        return AGX_OK;
+    }
+    if (!d_scratch) return AGX_ERR_NULL_POINTER;
+    if (d_scratch == d_a || d_scratch == d_b || d_scratch == d_c) return AGX_ERR_BAD_ARGUMENT;
     int rc;
     // scratch <- NTT(a); c <- NTT(b) (a is dead by now, so c may alias it); c <- c o scratch; c <- INTT(c)
     if ((rc = agx_ntt_forward(plan, d_a, d_scratch, batch, stream))) return rc;

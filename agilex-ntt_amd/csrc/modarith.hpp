@@ -198,4 +198,56 @@ __device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k,
     }
 }
 
+// w*d - c*q (mod 2^64) with the quotient estimate of the chosen arithmetic:
+// exact -> [0,2q), fast -> [0,4q); d may be any 64-bit value
+template <bool FAST>
+__device__ __forceinline__ uint64_t mul_shoup_form(uint64_t d, uint64_t w, uint64_t wp, const bf_consts& k) {
+    const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
+    uint64_t c;
+    if constexpr (FAST) {
+        c = mul64(p1, d1);
+        c = add64_32(c, __umulhi(d0, p1), k.one_a);
+        c = add64_32(c, __umulhi(d1, p0), k.one_b);
+    } else {
+        const uint32_t t = __umulhi(d0, p0);
+        const uint64_t m1 = add64_32(mul64(p1, d0), t, k.one_a);
+        const uint64_t m2 = add64_32(mul64(p0, d1), (uint32_t)m1, k.one_b);
+        c = add64_32(mul64(p1, d1), (uint32_t)(m1 >> 32), k.one_a);
+        c = add64_32(c, (uint32_t)(m2 >> 32), k.one_b);
+    }
+    return fold_product(0, d, w, c, k);
+}
+
+// Gentleman-Sande butterfly of the inverse transform, coefficients in [0,m)
+// (m = 2q exact / 4q fast): x' = x + y - [x+y >= m] m,  y' = w (x - y + m) lazily reduced.
+template <bool FAST>
+__device__ __forceinline__ void gs_butterfly_form(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k) {
+    const uint64_t s = x + y;
+    const uint64_t d = x + k.m - y;
+    if constexpr (FAST) x = csub_sign(s, k);
+    else x = csub(s, k.m);
+    y = mul_shoup_form<FAST>(d, w, wp, k);
+}
+
+// last inverse stage with n^-1 folded in: x' = (x + y) n^-1, y' = (x - y) w n^-1
+template <bool FAST>
+__device__ __forceinline__ void gs_last_form(uint64_t& x, uint64_t& y, uint64_t ninv, uint64_t ninv_p,
+                                             uint64_t w1n, uint64_t w1n_p, const bf_consts& k) {
+    const uint64_t s = x + y;
+    const uint64_t d = x + k.m - y;
+    x = mul_shoup_form<FAST>(s, ninv, ninv_p, k);
+    y = mul_shoup_form<FAST>(d, w1n, w1n_p, k);
+}
+
+// [0,m) -> [0,q) after the inverse transform
+template <bool FAST>
+__device__ __forceinline__ uint64_t reduce_final_inv(uint64_t v, const bf_consts& k, const final_consts& f) {
+    if constexpr (FAST) {
+        v = csub_sign_c(v, f.q2, f.nq2);
+        return csub_sign_c(v, f.q1, f.nq1);
+    } else {
+        return csub(v, k.q);
+    }
+}
+
 }  // namespace agx

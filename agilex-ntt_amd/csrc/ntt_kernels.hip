@@ -351,114 +351,262 @@ __device__ __forceinline__ twpair load_uniform(const twpair* p) {
     return r;
 }
 
+// per-frame state shared by the second-generation kernels
+template <int L, int R, bool FAST>
+struct rb2_frame {
+    using G = rb2_geom<L, R>;
+    static constexpr int C = G::C, T = G::T, NP = G::NP;
+    uint32_t tid, blk, split_log;
+    uint64_t* slab;
+    bf_consts k;
+    final_consts fc;
+
+    __device__ __forceinline__ void init_consts(uint64_t q) {
+        k.q = q;
+        k.nq = 0 - q;
+        k.m = FAST ? (q << 2) : (q << 1);
+        k.nm = opaque_sgpr64(0 - k.m);
+        k.one_a = opaque_one<0>();
+        k.one_b = opaque_one<1>();
+        fc.q2 = q << 1;
+        fc.nq2 = opaque_sgpr64(0 - fc.q2);
+        fc.q1 = q;
+        fc.nq1 = opaque_sgpr64(0 - fc.q1);
+    }
+
+    // image word of (pass p, register r) for this thread
+    template <int p>
+    __device__ __forceinline__ uint32_t sbase() const {
+        constexpr int rlo = G::rlo(p);
+        return lds_swz((tid & ((1u << rlo) - 1u)) | ((tid >> rlo) << (rlo + R)));
+    }
+
+    // fetch the twiddles of pass p: scalar loads when the column is wave-uniform
+    template <int p>
+    struct tw_src {
+        twpair tw[C];
+        const twpair* col;
+        uint32_t hstride;
+    };
+    template <int p>
+    __device__ __forceinline__ void fetch(tw_src<p>& t, const twpair* tbl) const {
+        constexpr int rlo = G::rlo(p), H = G::H(p);
+        const uint32_t high = tid >> rlo;
+        if constexpr (rlo >= 6) {
+            const uint32_t hcol = (uint32_t)__builtin_amdgcn_readfirstlane((int)high);
+            const twpair* ucol = tbl + G::table_off(p) * (1u << split_log) + ((size_t)blk * H + hcol) * C;
+#pragma unroll
+            for (int j = 1; j < C; ++j) t.tw[j] = load_uniform(ucol + j);      // merged into wide s_loads
+            t.col = nullptr;
+            t.hstride = 0;
+        } else {
+            t.col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + high;
+            t.hstride = (uint32_t)H << split_log;
+        }
+    }
+    template <int p>
+    __device__ __forceinline__ twpair twiddle(const tw_src<p>& t, int j) const {
+        if constexpr (G::rlo(p) >= 6) return t.tw[j];
+        else return t.col[(size_t)j * t.hstride];
+    }
+
+    template <int p>
+    __device__ __forceinline__ void image_read(uint64_t (&x)[C]) const {
+        const uint32_t sb = sbase<p>();
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = slab[sb ^ lds_swz((uint32_t)r << G::rlo(p))];
+    }
+    template <int p>
+    __device__ __forceinline__ void image_write(const uint64_t (&x)[C]) const {
+        const uint32_t sb = sbase<p>();
+#pragma unroll
+        for (int r = 0; r < C; ++r) slab[sb ^ lds_swz((uint32_t)r << G::rlo(p))] = x[r];
+    }
+    // order the read side of the exchange between passes p and p+1 (either direction)
+    template <int p>
+    __device__ __forceinline__ void exchange_sync() const {
+        if constexpr (!G::exchange_is_wave_local(p)) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
+    }
+
+    // x in pass-0 layout (element tid + T*r, any values in [0,2m)) -> forward transform, x in the
+    // last pass's layout (elements tid*C .. tid*C+C-1), fully reduced
+    __device__ __forceinline__ void forward(uint64_t (&x)[C], const twpair* tbl) const {
+        static_for<0, NP>([&](auto P) {
+            constexpr int p = P;
+            constexpr int rlo = G::rlo(p), hi = G::hi(p);
+            tw_src<p> t;
+            fetch<p>(t, tbl);
+            if constexpr (p > 0) image_read<p>(x);
+            static_for<0, hi - rlo + 1>([&](auto S) {
+                constexpr int rb = (hi - rlo) - S;        // gap bits descend: Cooley-Tukey
+                constexpr int kk = R - 1 - rb;
+                constexpr bool last_stage = (rlo + rb) == 0;
+#pragma unroll
+                for (int r0 = 0; r0 < C; ++r0) {
+                    if ((r0 >> rb) & 1) continue;
+                    const int r1 = r0 | (1 << rb);
+                    const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
+                    if constexpr (FAST) ct_butterfly_fast(x[r0], x[r1], w.x, w.y, k);
+                    else ct_butterfly_exact(x[r0], x[r1], w.x, w.y, k);
+                    if constexpr (last_stage) {
+                        x[r0] = reduce_final<FAST>(x[r0], k, fc);
+                        x[r1] = reduce_final<FAST>(x[r1], k, fc);
+                    }
+                }
+            });
+            if constexpr (p < NP - 1) {
+                // A thread overwrites exactly the image words it read for this pass, so no other
+                // thread can still need them: only the read side of an exchange has to be ordered.
+                image_write<p>(x);
+                exchange_sync<p>();
+            }
+        });
+    }
+
+    // x in the last pass's layout, values in [0,m) -> inverse transform (Gentleman-Sande, gap bits
+    // ascending), x in pass-0 layout, fully reduced.  With split_log = 0 the top stage also
+    // multiplies by n^-1; otherwise inv_global_stage finishes the transform.
+    __device__ __forceinline__ void inverse(uint64_t (&x)[C], const twpair* itbl, const prime_consts& pc) const {
+        static_for<0, NP>([&](auto Q) {
+            constexpr int p = NP - 1 - Q;
+            constexpr int rlo = G::rlo(p), hi = G::hi(p);
+            tw_src<p> t;
+            fetch<p>(t, itbl);
+            if constexpr (p < NP - 1) image_read<p>(x);
+            static_for<0, hi - rlo + 1>([&](auto S) {
+                constexpr int rb = S;                     // gap bits ascend
+                constexpr int kk = R - 1 - rb;
+                constexpr bool top_stage = (rlo + rb) == L - 1;
+#pragma unroll
+                for (int r0 = 0; r0 < C; ++r0) {
+                    if ((r0 >> rb) & 1) continue;
+                    const int r1 = r0 | (1 << rb);
+                    if (top_stage && split_log == 0) {
+                        gs_last_form<FAST>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k);
+                    } else {
+                        const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
+                        gs_butterfly_form<FAST>(x[r0], x[r1], w.x, w.y, k);
+                    }
+                    if constexpr (top_stage) {
+                        x[r0] = reduce_final_inv<FAST>(x[r0], k, fc);
+                        x[r1] = reduce_final_inv<FAST>(x[r1], k, fc);
+                    }
+                }
+            });
+            if constexpr (p > 0) {
+                image_write<p>(x);
+                exchange_sync<p - 1>();
+            }
+        });
+    }
+
+    // last-pass layout <-> lane-contiguous global accesses, through the image (wave-local: after
+    // the last forward pass / before the first inverse pass a wave owns 64*C contiguous elements)
+    __device__ __forceinline__ void store_last_layout(const uint64_t (&x)[C], uint64_t* __restrict__ out, int64_t base, bool live) const {
+        static_assert(G::last_pass_wave_contiguous(), "store path assumes a wave-contiguous last pass");
+#pragma unroll
+        for (int r = 0; r < C; ++r) slab[lds_swz((tid << R) | (uint32_t)r)] = x[r];
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            const uint32_t wbase = (tid >> 6) << (6 + R), lane = tid & 63u;
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                const uint32_t e = wbase + lane + 64u * (uint32_t)r;
+                out[base + e] = slab[lds_swz(e)];
+            }
+        }
+    }
+    __device__ __forceinline__ void load_last_layout(uint64_t (&x)[C], const uint64_t* __restrict__ in, int64_t base) const {
+        const uint32_t wbase = (tid >> 6) << (6 + R), lane = tid & 63u;
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            const uint32_t e = wbase + lane + 64u * (uint32_t)r;
+            uint64_t v = in[base + e];
+            if constexpr (!FAST) v = csub(v, k.m);    // exact form wants [0,2q); inputs may be < 4q
+            slab[lds_swz(e)] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = slab[lds_swz((tid << R) | (uint32_t)r)];
+    }
+};
+
+#define AGX_RB2_PROLOGUE                                                                          \
+    using F = rb2_frame<L, R, ARITH == 1>;                                                        \
+    constexpr int C = F::C, T = F::T;                                                             \
+    static_assert(T >= 64, "one frame must span whole waves");                                    \
+    F f;                                                                                          \
+    f.tid = threadIdx.x & (T - 1);                                                                \
+    const uint32_t slot = threadIdx.x / T;                                                        \
+    uint64_t fx = (uint64_t)blockIdx.x * PPB + slot;                                              \
+    const bool live = fx < frames_x;                                                              \
+    if (!live) fx = frames_x - 1;                                                                 \
+    const uint32_t prime = blockIdx.y;                                                            \
+    const uint64_t poly = fx >> split_log;                                                        \
+    f.blk = (uint32_t)(fx & ((1u << split_log) - 1u));                                            \
+    f.split_log = split_log;                                                                      \
+    f.init_consts(consts[prime].q);                                                               \
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds) + ((size_t)slot << L);                      \
+    const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)f.blk << L)
+
 template <int L, int R, int PPB, int ARITH, int MINW>
 __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
         const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
         uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
         int64_t prime_stride, int64_t poly_stride) {
-    using G = rb2_geom<L, R>;
-    constexpr int C = G::C, T = G::T, NP = G::NP;
-    constexpr bool FAST = ARITH == 1;
-    static_assert(T >= 64, "one frame must span whole waves");
-    uint64_t* lds = reinterpret_cast<uint64_t*>(agx_dyn_lds);
-
-    const uint32_t tid = threadIdx.x & (T - 1);
-    const uint32_t slot = threadIdx.x / T;
-    uint64_t fx = (uint64_t)blockIdx.x * PPB + slot;
-    const bool live = fx < frames_x;
-    if (!live) fx = frames_x - 1;
-    const uint32_t prime = blockIdx.y;
-    const uint64_t poly = fx >> split_log;
-    const uint32_t blk = (uint32_t)(fx & ((1u << split_log) - 1u));
-    bf_consts k;
-    k.q = consts[prime].q;
-    k.nq = 0 - k.q;
-    k.m = FAST ? (k.q << 2) : (k.q << 1);
-    k.nm = opaque_sgpr64(0 - k.m);
-    k.one_a = opaque_one<0>();
-    k.one_b = opaque_one<1>();
-    final_consts fc;
-    fc.q2 = k.q << 1;
-    fc.nq2 = opaque_sgpr64(0 - fc.q2);
-    fc.q1 = k.q;
-    fc.nq1 = opaque_sgpr64(0 - fc.q1);
-    const twpair* tbl = tw_rb + (size_t)prime * pairs_per_prime;
-    const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)blk << L);
-    uint64_t* slab = lds + ((size_t)slot << L);
-
+    AGX_RB2_PROLOGUE;
     uint64_t x[C];
 #pragma unroll
-    for (int r = 0; r < C; ++r) x[r] = in[base + tid + (uint32_t)r * T];
+    for (int r = 0; r < C; ++r) x[r] = in[base + f.tid + (uint32_t)r * T];
+    f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
+    f.store_last_layout(x, out, base, live);
+}
 
-    static_for<0, NP>([&](auto P) {
-        constexpr int p = P;
-        constexpr int rlo = G::rlo(p), hi = G::hi(p), H = G::H(p);
-        constexpr bool uniform = rlo >= 6;    // tid >> rlo is the same for the 64 lanes of a wave
-        const uint32_t low = tid & ((1u << rlo) - 1u), high = tid >> rlo;
-        const uint32_t sbase = lds_swz(low | (high << (rlo + R)));
-        // wave-uniform passes fetch their 2^R - 1 table entries up front with wide scalar loads;
-        // per-lane passes load each entry where it is used (prefetching all of them costs 28 VGPRs
-        // and spills at the 64-register budget of 8 waves/SIMD)
-        twpair tw[C];
-        const twpair* col = nullptr;
-        uint32_t hstride = 0;
-        if constexpr (uniform) {
-            const uint32_t hcol = (uint32_t)__builtin_amdgcn_readfirstlane((int)high);
-            const twpair* ucol = tbl + G::table_off(p) * (1u << split_log) + ((size_t)blk * H + hcol) * C;
-#pragma unroll
-            for (int j = 1; j < C; ++j) tw[j] = load_uniform(ucol + j);      // merged into wide s_loads
-        } else {
-            col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + high;
-            hstride = (uint32_t)H << split_log;
-        }
-        if constexpr (p > 0) {
-#pragma unroll
-            for (int r = 0; r < C; ++r) x[r] = slab[sbase ^ lds_swz((uint32_t)r << rlo)];
-        }
-        static_for<0, hi - rlo + 1>([&](auto S) {
-            constexpr int rb = (hi - rlo) - S;
-            constexpr int kk = R - 1 - rb;
-            constexpr bool last_stage = (rlo + rb) == 0;
-#pragma unroll
-            for (int r0 = 0; r0 < C; ++r0) {
-                if ((r0 >> rb) & 1) continue;
-                const int r1 = r0 | (1 << rb);
-                const int j = (1 << kk) + (r0 >> (rb + 1));
-                twpair w;
-                if constexpr (uniform) w = tw[j];
-                else w = col[(size_t)j * hstride];
-                if constexpr (FAST) ct_butterfly_fast(x[r0], x[r1], w.x, w.y, k);
-                else ct_butterfly_exact(x[r0], x[r1], w.x, w.y, k);
-                if constexpr (last_stage) {
-                    x[r0] = reduce_final<FAST>(x[r0], k, fc);
-                    x[r1] = reduce_final<FAST>(x[r1], k, fc);
-                }
-            }
-        });
-        if constexpr (p < NP - 1) {
-            // A thread overwrites exactly the image words it read for this pass, so no other
-            // thread can still need them: only the read side of an exchange has to be ordered.
-#pragma unroll
-            for (int r = 0; r < C; ++r) slab[sbase ^ lds_swz((uint32_t)r << rlo)] = x[r];
-            if constexpr (!G::exchange_is_wave_local(p)) __syncthreads();
-            else __builtin_amdgcn_wave_barrier();
-        }
-    });
-
-    // last pass: rlo = 0, thread holds coefficients [tid*C, tid*C + C); a wave holds 64*C
-    // contiguous ones.  Through the image once more so that global stores are lane-contiguous.
-    static_assert(G::last_pass_wave_contiguous(), "store path assumes a wave-contiguous last pass");
-#pragma unroll
-    for (int r = 0; r < C; ++r) slab[lds_swz((tid << R) | (uint32_t)r)] = x[r];
-    __builtin_amdgcn_wave_barrier();
+template <int L, int R, int PPB, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
+inv_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+        const prime_consts* __restrict__ consts, const twpair* __restrict__ itw_rb,
+        uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
+        int64_t prime_stride, int64_t poly_stride) {
+    AGX_RB2_PROLOGUE;
+    uint64_t x[C];
+    f.load_last_layout(x, in, base);
+    f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, consts[prime]);
     if (live) {
-        const uint32_t wbase = (tid >> 6) << (6 + R), lane = tid & 63u;
 #pragma unroll
-        for (int r = 0; r < C; ++r) {
-            const uint32_t e = wbase + lane + 64u * (uint32_t)r;
-            out[base + e] = slab[lds_swz(e)];
-        }
+        for (int r = 0; r < C; ++r) out[base + f.tid + (uint32_t)r * T] = x[r];
+    }
+}
+
+// c = INTT(NTT(a) o NTT(b)) for one frame without leaving the chip: both forward transforms end in
+// the same register layout, the product is taken there, and the inverse starts from it (no staging
+// through the image at either seam).  HBM traffic 24n bytes per product.
+template <int L, int R, int PPB, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)) * PPB, (MINW > 5 ? 5 : MINW))   // one frame more in registers
+polymul_rb2(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ c,
+            const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb, const twpair* __restrict__ itw_rb,
+            uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride) {
+    constexpr uint32_t split_log = 0;
+    AGX_RB2_PROLOGUE;
+    const prime_consts pc = consts[prime];
+    const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
+    uint64_t xa[C], xb[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) xa[r] = a[base + f.tid + (uint32_t)r * T];
+    f.forward(xa, tw_rb + (size_t)prime * pairs_per_prime);
+    // b is fetched only now: holding it across NTT(a) would cost 2^R more register pairs and spill
+#pragma unroll
+    for (int r = 0; r < C; ++r) xb[r] = b[base + f.tid + (uint32_t)r * T];
+    __syncthreads();   // the image is reused: every wave must be done reading NTT(a)'s exchanges
+    f.forward(xb, tw_rb + (size_t)prime * pairs_per_prime);
+#pragma unroll
+    for (int r = 0; r < C; ++r) xa[r] = mul_mod_barrett(xa[r], xb[r], bk);
+    f.inverse(xa, itw_rb + (size_t)prime * pairs_per_prime, pc);
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < C; ++r) c[base + f.tid + (uint32_t)r * T] = xa[r];
     }
 }
 
@@ -517,6 +665,8 @@ struct rb_entry {
     hipError_t (*launch)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     hipError_t (*init)();
     int arith;   // 0: exact (reference op sequence, q < 2^62); 1: fast (q <= 2^61)
+    hipError_t (*launch_inv)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    hipError_t (*launch_mul)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
 };
 
 template <int L, int R, bool col_major = false>
@@ -575,22 +725,46 @@ hipError_t launch_rb2_t(const plan_view& pv, const uint64_t* in, uint64_t* out, 
     return hipGetLastError();
 }
 
+
+template <int L, int R, int PPB, int ARITH, int MINW>
+hipError_t launch_inv_rb2_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    const uint64_t frames_x = fl.batch << pv.rb.log_split;
+    dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
+    hipLaunchKernelGGL((inv_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), ((size_t)8 << L) * PPB, s, in, out, pv.consts,
+                       pv.itw_rb, pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
+template <int L, int R, int PPB, int ARITH, int MINW>
+hipError_t launch_mul_rb2_t(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    dim3 grid((unsigned)((fl.batch + PPB - 1) / PPB), pv.num_primes);
+    hipLaunchKernelGGL((polymul_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), ((size_t)8 << L) * PPB, s, a, b, c, pv.consts,
+                       pv.tw_rb, pv.itw_rb, pv.rb.pairs_per_prime, fl.batch, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
 template <int L, int R, int PPB, int ARITH, int MINW>
 hipError_t init_rb2_t() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2<L, R, PPB, ARITH, MINW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)8 << L) * PPB));
+    const int bytes = (int)(((size_t)8 << L) * PPB);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2<L, R, PPB, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2<L, R, PPB, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polymul_rb2<L, R, PPB, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e;
 }
 
 template <int L, int R, int PPB, int ARITH, int MINW>
 constexpr rb_entry make_entry2(int id) {
     return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, ((size_t)8 << L) * PPB,
-                    &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>, ARITH};
+                    &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>, ARITH,
+                    &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>};
 }
 
 template <int L, int R, int PPB, bool STAGE_OUT, int MINW>
 constexpr rb_entry make_entry(int id) {
     return rb_entry{id, L, R, PPB, STAGE_OUT, MINW, (uint32_t)rb_geom<L, R>::table_pairs, (size_t)rb_geom<L, R>::lds_elems * 8 * PPB,
-                    &build_table_t<L, R>, &launch_rb_t<L, R, PPB, STAGE_OUT, MINW>, &init_rb_t<L, R, PPB, STAGE_OUT, MINW>, 0};
+                    &build_table_t<L, R>, &launch_rb_t<L, R, PPB, STAGE_OUT, MINW>, &init_rb_t<L, R, PPB, STAGE_OUT, MINW>, 0, nullptr, nullptr};
 }
 
 const rb_entry kRbEntries[] = {
@@ -729,6 +903,35 @@ hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint
     const rb_entry* e = rb_lookup(pv.rb.config_id);
     if (e) return e->launch(pv, src, out, fl, s);
     return hipErrorInvalidValue;
+}
+
+bool regblock_has_inverse(const regblock_layout& rb) {
+    const rb_entry* e = rb_lookup(rb.config_id);
+    return e && e->launch_inv;
+}
+
+bool regblock_has_polymul(const regblock_layout& rb) {
+    const rb_entry* e = rb_lookup(rb.config_id);
+    return e && e->launch_mul && rb.log_split == 0 && rb.log_local <= 13;   // 2^14: 1024 threads x 128 VGPRs cannot hold two frames
+}
+
+hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    const rb_entry* e = rb_lookup(pv.rb.config_id);
+    if (!e || !e->launch_inv || !pv.itw_rb) return hipErrorInvalidValue;
+    hipError_t err = e->launch_inv(pv, in, out, fl, s);
+    if (err != hipSuccess) return err;
+    for (int st = pv.rb.log_split - 1; st >= 0; --st) {   // stages with a gap wider than the resident block
+        dim3 g2(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);
+        hipLaunchKernelGGL(inv_global_stage, g2, dim3(256), 0, s, out, pv.consts, pv.itw, pv.log_n, (uint32_t)st, fl.batch,
+                           fl.prime_stride, fl.poly_stride);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_polymul_regblock(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, const frame_layout& fl, hipStream_t s) {
+    const rb_entry* e = rb_lookup(pv.rb.config_id);
+    if (!e || !e->launch_mul || !pv.itw_rb || pv.rb.log_split != 0) return hipErrorInvalidValue;
+    return e->launch_mul(pv, a, b, c, fl, s);
 }
 
 hipError_t launch_pointwise(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, uint64_t batch, hipStream_t s) {

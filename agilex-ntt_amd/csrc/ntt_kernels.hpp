@@ -34,6 +34,7 @@ struct plan_view {
     const ulonglong2* itw = nullptr;       // [P][n] {w,w'} natural index   (inverse) or null
     regblock_layout rb;                    // forward register-blocked layout
     const ulonglong2* tw_rb = nullptr;     // [P][rb.pairs_per_prime]
+    const ulonglong2* itw_rb = nullptr;    // same layout from the inverse tables, or null
 };
 
 struct frame_layout {
@@ -52,6 +53,10 @@ hipError_t kernels_init();  // one-time function attributes (large dynamic LDS)
 hipError_t launch_forward_radix2(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
 hipError_t launch_inverse_radix2(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
 hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
+bool regblock_has_inverse(const regblock_layout& rb);
+bool regblock_has_polymul(const regblock_layout& rb);   // fused NTT -> pointwise -> INTT in one kernel
+hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
+hipError_t launch_polymul_regblock(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, const frame_layout& fl, hipStream_t s);
 hipError_t launch_pointwise(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, uint64_t batch, hipStream_t s);
 hipError_t launch_fill(const plan_view& pv, uint64_t* out, uint64_t batch, uint64_t first_poly, uint64_t seed, hipStream_t s);
 

@@ -111,7 +111,8 @@ int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint
 int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                       uint64_t batch, void* stream);
 /* c = a * b in Z_q[X]/(X^n + 1) = INTT(NTT(a) o NTT(b)); dense layout; c may alias a or b.
- * d_scratch: num_primes*batch*n elements of device memory owned by the caller, distinct from a, b, c. */
+ * d_scratch: num_primes*batch*n elements of device memory owned by the caller, distinct from a, b, c;
+ * only used (and may be NULL) when n has no fused kernel: today that is n < 1024 and n = 32768. */
 int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                     uint64_t* d_scratch, uint64_t batch, void* stream);
 

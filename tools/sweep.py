@@ -21,6 +21,7 @@ ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--primes", type=int, default=4)
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--slabs", type=int, default=4)
+ap.add_argument("--op", choices=["fwd", "inv", "mul"], default="fwd")
 args = ap.parse_args()
 N, P, B, SLABS = args.n, args.primes, args.batch, args.slabs
 ids = args.ids or [2, 5, 6, 7, 8, 9, 10, 11]
@@ -32,9 +33,22 @@ slabs = [torch.empty(per, dtype=torch.int64, device="cuda") for _ in range(SLABS
 for i, s in enumerate(slabs):
     plan.fill_synthetic(s.data_ptr(), B, i * B, 42, stream)
 ref_in = slabs[0].clone()
+ref_in2 = slabs[1 % SLABS].clone()
+scratch = torch.empty_like(ref_in)
 ref = torch.empty_like(ref_in)
+
+
+def run(src, dst, src2=None):
+    if args.op == "fwd":
+        plan.forward(src.data_ptr(), dst.data_ptr(), B, stream)
+    elif args.op == "inv":
+        plan.inverse(src.data_ptr(), dst.data_ptr(), B, stream)
+    else:
+        plan.polymul(src.data_ptr(), (src2 if src2 is not None else src).data_ptr(), dst.data_ptr(), scratch.data_ptr(), B, stream)
+
+
 plan.set_variant(agx.VARIANT_LDS_RADIX2)
-plan.forward(ref_in.data_ptr(), ref.data_ptr(), B, stream)
+run(ref_in, ref, ref_in2)
 torch.cuda.synchronize()
 out = torch.empty_like(ref_in)
 ok = {}
@@ -45,7 +59,7 @@ def select(k):
 for k in ids:
     select(k)
     out.zero_()
-    plan.forward(ref_in.data_ptr(), out.data_ptr(), B, stream)
+    run(ref_in, out, ref_in2)
     torch.cuda.synchronize()
     ok[k] = bool(torch.equal(out, ref))
 times = {k: [] for k in ids}
@@ -53,12 +67,11 @@ for rnd in range(5):
     for k in ids:
         select(k)
         for i in range(3):
-            plan.forward(slabs[i % SLABS].data_ptr(), slabs[i % SLABS].data_ptr(), B, stream)
+            run(slabs[i % SLABS], slabs[i % SLABS], slabs[(i + 1) % SLABS])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(20):
-            s = slabs[i % SLABS]
-            plan.forward(s.data_ptr(), s.data_ptr(), B, stream)
+            run(slabs[i % SLABS], slabs[i % SLABS], slabs[(i + 1) % SLABS])
         e1.record()
         torch.cuda.synchronize()
         times[k].append(e0.elapsed_time(e1) / 20)
@@ -67,4 +80,5 @@ for k in ids:
     t = sorted(times[k])
     mn, md = t[0], t[len(t) // 2]
     rate = P * B / (md * 1e-3)
-    print(f"{k:>3} {str(ok[k]):>9} {mn:8.4f} {md:8.4f} {rate / 1e6:8.2f} {rate * 16 * N / 1e9:8.1f} {rate * 16 * N / 8e12 * 100:7.2f}")
+    bpu = (24 if args.op == "mul" else 16) * N     # algorithmic bytes per unit
+    print(f"{k:>3} {str(ok[k]):>9} {mn:8.4f} {md:8.4f} {rate / 1e6:8.2f} {rate * bpu / 1e9:8.1f} {rate * bpu / 8e12 * 100:7.2f}")
