@@ -158,9 +158,16 @@ __device__ __forceinline__ void ct_butterfly_exact(uint64_t& x, uint64_t& y, uin
 // at most 2, so Q~ = w*y - c~*q lies in [0,4q); coefficients are kept in [0,8q) with m = 4q:
 //   tx = x - (x >= 4q ? 4q : 0) < 4q,  x' = tx + Q~ < 8q,  y' = tx + 4q - Q~ in (0,8q).
 // Same residues as the exact form at every stage, so the fully reduced outputs are identical.
+// x in [0,2m) -> x - (x >= m ? m : 0) by selecting on the sign of x - m (compare + two selects)
+__device__ __forceinline__ uint64_t csub_select(uint64_t x, const bf_consts& k) {
+    const uint64_t d = x + k.nm;
+    return (int64_t)d < 0 ? x : d;
+}
+
+template <bool SEL = false>
 __device__ __forceinline__ void ct_butterfly_fast(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k) {
     const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
-    const uint64_t tx = csub_sign(x, k);                                    // m = 4q <= 2^63
+    const uint64_t tx = SEL ? csub_select(x, k) : csub_sign(x, k);          // m = 4q <= 2^63
     uint64_t c = mul64(p1, y1);
     c = add64_32(c, __umulhi(y0, p1), k.one_a);
     c = add64_32(c, __umulhi(y1, p0), k.one_b);
@@ -220,11 +227,11 @@ __device__ __forceinline__ uint64_t mul_shoup_form(uint64_t d, uint64_t w, uint6
 
 // Gentleman-Sande butterfly of the inverse transform, coefficients in [0,m)
 // (m = 2q exact / 4q fast): x' = x + y - [x+y >= m] m,  y' = w (x - y + m) lazily reduced.
-template <bool FAST>
+template <bool FAST, bool SEL = false>
 __device__ __forceinline__ void gs_butterfly_form(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k) {
     const uint64_t s = x + y;
     const uint64_t d = x + k.m - y;
-    if constexpr (FAST) x = csub_sign(s, k);
+    if constexpr (FAST) x = SEL ? csub_select(s, k) : csub_sign(s, k);
     else x = csub(s, k.m);
     y = mul_shoup_form<FAST>(d, w, wp, k);
 }

@@ -15,6 +15,7 @@
 #include "ntt_kernels.hpp"
 #include "modarith.hpp"
 
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -351,11 +352,21 @@ __device__ __forceinline__ twpair load_uniform(const twpair* p) {
     return r;
 }
 
+// option bits of the second-generation kernels (A/B switches; the tuned defaults are in the registry)
+constexpr int kOptPad = 1;       // padded LDS image, exchanges addressed base + immediate offset
+constexpr int kOptSelect = 2;    // conditional subtract by compare + select instead of sign mask
+
 // per-frame state shared by the second-generation kernels
-template <int L, int R, bool FAST>
+template <int L, int R, bool FAST, int OPT = 0>
 struct rb2_frame {
     using G = rb2_geom<L, R>;
     static constexpr int C = G::C, T = G::T, NP = G::NP;
+    static constexpr bool PAD = (OPT & kOptPad) != 0, SEL = (OPT & kOptSelect) != 0;
+    static constexpr uint32_t slab_elems = PAD ? (1u << L) + (1u << (L - 4)) : (1u << L);
+    // image word of coefficient e; both forms are additive over disjoint bit fields, which is what
+    // lets an exchange address register r as (thread base) combined with a compile-time constant
+    static __device__ __forceinline__ constexpr uint32_t img(uint32_t e) { return PAD ? e + (e >> 4) : lds_swz(e); }
+    static __device__ __forceinline__ constexpr uint32_t join(uint32_t base, uint32_t delta) { return PAD ? base + delta : base ^ delta; }
     uint32_t tid, blk, split_log;
     uint64_t* slab;
     bf_consts k;
@@ -378,7 +389,7 @@ struct rb2_frame {
     template <int p>
     __device__ __forceinline__ uint32_t sbase() const {
         constexpr int rlo = G::rlo(p);
-        return lds_swz((tid & ((1u << rlo) - 1u)) | ((tid >> rlo) << (rlo + R)));
+        return img((tid & ((1u << rlo) - 1u)) | ((tid >> rlo) << (rlo + R)));
     }
 
     // fetch the twiddles of pass p: scalar loads when the column is wave-uniform
@@ -413,14 +424,12 @@ struct rb2_frame {
     template <int p>
     __device__ __forceinline__ void image_read(uint64_t (&x)[C]) const {
         const uint32_t sb = sbase<p>();
-#pragma unroll
-        for (int r = 0; r < C; ++r) x[r] = slab[sb ^ lds_swz((uint32_t)r << G::rlo(p))];
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; x[r] = slab[join(sb, img((uint32_t)r << G::rlo(p)))]; });
     }
     template <int p>
     __device__ __forceinline__ void image_write(const uint64_t (&x)[C]) const {
         const uint32_t sb = sbase<p>();
-#pragma unroll
-        for (int r = 0; r < C; ++r) slab[sb ^ lds_swz((uint32_t)r << G::rlo(p))] = x[r];
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; slab[join(sb, img((uint32_t)r << G::rlo(p)))] = x[r]; });
     }
     // order the read side of the exchange between passes p and p+1 (either direction)
     template <int p>
@@ -431,37 +440,56 @@ struct rb2_frame {
 
     // x in pass-0 layout (element tid + T*r, any values in [0,2m)) -> forward transform, x in the
     // last pass's layout (elements tid*C .. tid*C+C-1), fully reduced
-    __device__ __forceinline__ void forward(uint64_t (&x)[C], const twpair* tbl) const {
-        static_for<0, NP>([&](auto P) {
+    // forward passes [P0, P1): pass P0 reads the image unless it is pass 0 (x already holds the
+    // pass-0 layout); every pass but the last writes the image; `sync_first` = order the exchange
+    // that precedes pass P0 (split out so a caller can put work between the write and the sync)
+    template <int P0, int P1>
+    __device__ __forceinline__ void forward_passes(uint64_t (&x)[C], const twpair* tbl, bool sync_last_write) const {
+        static_for<P0, P1>([&](auto P) {
             constexpr int p = P;
             constexpr int rlo = G::rlo(p), hi = G::hi(p);
             tw_src<p> t;
             fetch<p>(t, tbl);
-            if constexpr (p > 0) image_read<p>(x);
+            if constexpr (p > 0) {
+                if constexpr (p == P0) exchange_sync<p - 1>();
+                image_read<p>(x);
+            }
             static_for<0, hi - rlo + 1>([&](auto S) {
                 constexpr int rb = (hi - rlo) - S;        // gap bits descend: Cooley-Tukey
                 constexpr int kk = R - 1 - rb;
                 constexpr bool last_stage = (rlo + rb) == 0;
-#pragma unroll
-                for (int r0 = 0; r0 < C; ++r0) {
-                    if ((r0 >> rb) & 1) continue;
-                    const int r1 = r0 | (1 << rb);
+                static_for<0, C / 2>([&](auto B) {
+                    // B-th butterfly of the stage: insert a 0 at register bit rb
+                    constexpr int b = B;
+                    constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
+                    constexpr int r1 = r0 | (1 << rb);
                     const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
-                    if constexpr (FAST) ct_butterfly_fast(x[r0], x[r1], w.x, w.y, k);
+                    if constexpr (FAST) ct_butterfly_fast<SEL>(x[r0], x[r1], w.x, w.y, k);
                     else ct_butterfly_exact(x[r0], x[r1], w.x, w.y, k);
                     if constexpr (last_stage) {
                         x[r0] = reduce_final<FAST>(x[r0], k, fc);
                         x[r1] = reduce_final<FAST>(x[r1], k, fc);
                     }
-                }
+                });
             });
             if constexpr (p < NP - 1) {
                 // A thread overwrites exactly the image words it read for this pass, so no other
                 // thread can still need them: only the read side of an exchange has to be ordered.
                 image_write<p>(x);
-                exchange_sync<p>();
+                if constexpr (p < P1 - 1) exchange_sync<p>();
             }
         });
+        (void)sync_last_write;
+    }
+    // x in pass-0 layout (element tid + T*r, any values in [0,2m)) -> forward transform, x in the
+    // last pass's layout (elements tid*C .. tid*C+C-1), fully reduced
+    __device__ __forceinline__ void forward(uint64_t (&x)[C], const twpair* tbl) const {
+        if constexpr (NP == 1) {
+            forward_passes<0, 1>(x, tbl, false);
+        } else {
+            forward_passes<0, 1>(x, tbl, false);
+            forward_passes<1, NP>(x, tbl, false);
+        }
     }
 
     // x in the last pass's layout, values in [0,m) -> inverse transform (Gentleman-Sande, gap bits
@@ -486,7 +514,7 @@ struct rb2_frame {
                         gs_last_form<FAST>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k);
                     } else {
                         const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
-                        gs_butterfly_form<FAST>(x[r0], x[r1], w.x, w.y, k);
+                        gs_butterfly_form<FAST, SEL>(x[r0], x[r1], w.x, w.y, k);
                     }
                     if constexpr (top_stage) {
                         x[r0] = reduce_final_inv<FAST>(x[r0], k, fc);
@@ -505,35 +533,31 @@ struct rb2_frame {
     // the last forward pass / before the first inverse pass a wave owns 64*C contiguous elements)
     __device__ __forceinline__ void store_last_layout(const uint64_t (&x)[C], uint64_t* __restrict__ out, int64_t base, bool live) const {
         static_assert(G::last_pass_wave_contiguous(), "store path assumes a wave-contiguous last pass");
-#pragma unroll
-        for (int r = 0; r < C; ++r) slab[lds_swz((tid << R) | (uint32_t)r)] = x[r];
+        const uint32_t own = img(tid << R);
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; slab[join(own, img((uint32_t)r))] = x[r]; });
         __builtin_amdgcn_wave_barrier();
         if (live) {
-            const uint32_t wbase = (tid >> 6) << (6 + R), lane = tid & 63u;
-#pragma unroll
-            for (int r = 0; r < C; ++r) {
-                const uint32_t e = wbase + lane + 64u * (uint32_t)r;
-                out[base + e] = slab[lds_swz(e)];
-            }
+            const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[base + e0 + 64u * (uint32_t)r] = slab[join(s0, img(64u * (uint32_t)r))]; });
         }
     }
     __device__ __forceinline__ void load_last_layout(uint64_t (&x)[C], const uint64_t* __restrict__ in, int64_t base) const {
-        const uint32_t wbase = (tid >> 6) << (6 + R), lane = tid & 63u;
+        const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            const uint32_t e = wbase + lane + 64u * (uint32_t)r;
-            uint64_t v = in[base + e];
+            uint64_t v = in[base + e0 + 64u * (uint32_t)r];
             if constexpr (!FAST) v = csub(v, k.m);    // exact form wants [0,2q); inputs may be < 4q
-            slab[lds_swz(e)] = v;
+            slab[join(s0, img(64u * (uint32_t)r))] = v;
         }
         __builtin_amdgcn_wave_barrier();
+        const uint32_t own = img(tid << R);
 #pragma unroll
-        for (int r = 0; r < C; ++r) x[r] = slab[lds_swz((tid << R) | (uint32_t)r)];
+        for (int r = 0; r < C; ++r) x[r] = slab[join(own, img((uint32_t)r))];
     }
 };
 
 #define AGX_RB2_PROLOGUE                                                                          \
-    using F = rb2_frame<L, R, ARITH == 1>;                                                        \
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;                                    \
     constexpr int C = F::C, T = F::T;                                                             \
     static_assert(T >= 64, "one frame must span whole waves");                                    \
     F f;                                                                                          \
@@ -547,7 +571,7 @@ struct rb2_frame {
     f.blk = (uint32_t)(fx & ((1u << split_log) - 1u));                                            \
     f.split_log = split_log;                                                                      \
     f.init_consts(consts[prime].q);                                                               \
-    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds) + ((size_t)slot << L);                      \
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds) + (size_t)slot * F::slab_elems;             \
     const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)f.blk << L)
 
 template <int L, int R, int PPB, int ARITH, int MINW>
@@ -714,11 +738,16 @@ hipError_t init_rb_t() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)rb_geom<L, R>::lds_elems * 8 * PPB));
 }
 
+template <int L, int R, int PPB, int ARITH>
+constexpr size_t rb2_lds_bytes() {
+    return (size_t)rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>::slab_elems * 8 * PPB;
+}
+
 template <int L, int R, int PPB, int ARITH, int MINW>
 hipError_t launch_rb2_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     const uint64_t frames_x = fl.batch << pv.rb.log_split;
-    const size_t lds = ((size_t)8 << L) * PPB;
+    const size_t lds = rb2_lds_bytes<L, R, PPB, ARITH>();
     dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
     hipLaunchKernelGGL((fwd_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts, pv.tw_rb,
                        pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride);
@@ -731,7 +760,8 @@ hipError_t launch_inv_rb2_t(const plan_view& pv, const uint64_t* in, uint64_t* o
     using G = rb_geom<L, R>;
     const uint64_t frames_x = fl.batch << pv.rb.log_split;
     dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
-    hipLaunchKernelGGL((inv_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), ((size_t)8 << L) * PPB, s, in, out, pv.consts,
+    const size_t lds = rb2_lds_bytes<L, R, PPB, ARITH>();
+    hipLaunchKernelGGL((inv_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts,
                        pv.itw_rb, pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride);
     return hipGetLastError();
 }
@@ -740,14 +770,15 @@ template <int L, int R, int PPB, int ARITH, int MINW>
 hipError_t launch_mul_rb2_t(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     dim3 grid((unsigned)((fl.batch + PPB - 1) / PPB), pv.num_primes);
-    hipLaunchKernelGGL((polymul_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), ((size_t)8 << L) * PPB, s, a, b, c, pv.consts,
+    const size_t lds = rb2_lds_bytes<L, R, PPB, ARITH>();
+    hipLaunchKernelGGL((polymul_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), lds, s, a, b, c, pv.consts,
                        pv.tw_rb, pv.itw_rb, pv.rb.pairs_per_prime, fl.batch, fl.prime_stride, fl.poly_stride);
     return hipGetLastError();
 }
 
 template <int L, int R, int PPB, int ARITH, int MINW>
 hipError_t init_rb2_t() {
-    const int bytes = (int)(((size_t)8 << L) * PPB);
+    const int bytes = (int)rb2_lds_bytes<L, R, PPB, ARITH>();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2<L, R, PPB, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2<L, R, PPB, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polymul_rb2<L, R, PPB, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -756,8 +787,8 @@ hipError_t init_rb2_t() {
 
 template <int L, int R, int PPB, int ARITH, int MINW>
 constexpr rb_entry make_entry2(int id) {
-    return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, ((size_t)8 << L) * PPB,
-                    &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>, ARITH,
+    return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, rb2_lds_bytes<L, R, PPB, ARITH>(),
+                    &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>, ARITH & 1,
                     &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>};
 }
 
@@ -781,16 +812,25 @@ const rb_entry kRbEntries[] = {
     make_entry<12, 4, 1, false, 6>(9),
     make_entry<12, 5, 2, false, 1>(10),
     make_entry<12, 4, 1, false, 5>(11),
-    make_entry2<12, 3, 1, 1, 8>(12),   // fast arithmetic, 8 waves/SIMD
+    make_entry2<12, 3, 1, 1, 8>(12),   // fast arithmetic, 8 waves/SIMD, XOR-swizzled image, sign-mask csub
     make_entry2<12, 3, 1, 0, 8>(13),   // exact arithmetic
     make_entry2<12, 3, 1, 1, 1>(14),
     make_entry2<12, 4, 1, 1, 1>(15),
     make_entry2<12, 4, 1, 1, 6>(16),
-    // second generation, other sizes (fast, exact)
+    // second generation, other sizes (fast, exact), first tuning
     make_entry2<10, 3, 4, 1, 8>(17), make_entry2<10, 3, 4, 0, 8>(18),
     make_entry2<11, 3, 2, 1, 8>(19), make_entry2<11, 3, 2, 0, 8>(20),
     make_entry2<13, 3, 1, 1, 8>(21), make_entry2<13, 3, 1, 0, 8>(22),
     make_entry2<14, 4, 1, 1, 4>(23), make_entry2<14, 4, 1, 0, 4>(24),
+    // option bits (ARITH = fast | options << 1): padded image + select-based csub measured best
+    make_entry2<12, 3, 1, 1 | (kOptPad << 1), 8>(25),
+    make_entry2<12, 3, 1, 1 | (kOptSelect << 1), 8>(26),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(27),
+    make_entry2<12, 3, 1, 0 | (kOptPad << 1), 8>(28),
+    make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29), make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
+    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31), make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
+    make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(33), make_entry2<13, 3, 1, 0 | (kOptPad << 1), 8>(34),
+    make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect) << 1), 4>(35), make_entry2<14, 4, 1, 0 | (kOptPad << 1), 4>(36),
 };
 constexpr int kNumRbEntries = sizeof(kRbEntries) / sizeof(kRbEntries[0]);
 
@@ -823,7 +863,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, bool allow_fast) {
         if (e && (e->log_local != log_local || (e->arith == 1 && !allow_fast))) e = nullptr;
     } else {
         // tuned defaults, best first; fast arithmetic only when every modulus is <= 2^61
-        static const int kDefaults[] = {12, 13, 17, 18, 19, 20, 21, 22, 23, 24, 0, 1, 2, 3, 4};
+        static const int kDefaults[] = {27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 12, 13, 17, 18, 19, 20, 21, 22, 23, 24, 0, 1, 2, 3, 4};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
             if (c && c->log_local == log_local && (c->arith == 0 || allow_fast)) { e = c; break; }
