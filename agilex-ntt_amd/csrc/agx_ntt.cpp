@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -19,7 +20,7 @@ struct agx_ntt_plan {
     int device = -1;
     int variant = AGX_VARIANT_AUTO;
     bool has_inverse = false;
-    bool all_le_61 = false;  // every modulus <= 2^61: the fast (8q-lazy) butterfly is legal
+    int arith_level = 0;     // 0 exact only; 1: every modulus <= 2^61 (8q-lazy legal); 2: <= 2^60 (16q-lazy legal)
     std::vector<uint64_t> moduli, psi;  // psi = 0 when the tables came from the caller
     prime_consts* d_consts = nullptr;
     ulonglong2* d_tw = nullptr;
@@ -119,16 +120,17 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     // and the tables honour the contract precon[j] = floor(twiddle[j] * 2^64 / q), twiddle[j] < q.
     // Tables that do not (e.g. the placeholders of the reference's main.cpp:49-55) get the exact
     // kernels, which repeat the reference's operations mod 2^64 whatever they are fed.
-    p->all_le_61 = true;
-    for (uint32_t k = 0; k < num_primes && p->all_le_61; ++k) {
+    p->arith_level = 2;
+    for (uint32_t k = 0; k < num_primes && p->arith_level > 0; ++k) {
         const uint64_t q = moduli[k];
-        if (q > (1ull << 61)) p->all_le_61 = false;
-        for (uint32_t j = 1; j < n && p->all_le_61; ++j) {
+        if (q > (1ull << 60)) p->arith_level = std::min(p->arith_level, 1);
+        if (q > (1ull << 61)) p->arith_level = 0;
+        for (uint32_t j = 1; j < n && p->arith_level > 0; ++j) {
             const uint64_t w = tw[(size_t)k * n + j];
-            if (w >= q || pre[(size_t)k * n + j] != shoup_quotient(w, q)) p->all_le_61 = false;
+            if (w >= q || pre[(size_t)k * n + j] != shoup_quotient(w, q)) p->arith_level = 0;
         }
     }
-    p->rb = regblock_choose(n, -1, p->all_le_61);
+    p->rb = regblock_choose(n, -1, p->arith_level);
     std::vector<ulonglong2> rb_pairs, irb_pairs;
     for (uint32_t k = 0; k < num_primes; ++k) {
         const uint64_t q = moduli[k];
@@ -253,7 +255,7 @@ int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant) {
     if (variant != AGX_VARIANT_AUTO && variant != AGX_VARIANT_LDS_RADIX2 && variant != AGX_VARIANT_REGBLOCK) return AGX_ERR_BAD_ARGUMENT;
     if (variant == AGX_VARIANT_REGBLOCK || variant == AGX_VARIANT_AUTO) {
         // (re)build the pass tables for the requested kernel configuration
-        const regblock_layout rb = regblock_choose(plan->n, config_id, plan->all_le_61);
+        const regblock_layout rb = regblock_choose(plan->n, config_id, plan->arith_level);
         if (!rb.valid()) {
             if (variant == AGX_VARIANT_REGBLOCK) return AGX_ERR_BAD_SIZE;
         } else if (rb.config_id != plan->rb.config_id) {

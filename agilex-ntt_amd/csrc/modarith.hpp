@@ -168,8 +168,7 @@ template <bool SEL = false>
 __device__ __forceinline__ void ct_butterfly_fast(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k) {
     const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
     const uint64_t tx = SEL ? csub_select(x, k) : csub_sign(x, k);          // m = 4q <= 2^63
-    uint64_t c = mul64(p1, y1);
-    c = add64_32(c, __umulhi(y0, p1), k.one_a);
+    uint64_t c = mad64(p1, y1, (uint64_t)__umulhi(y0, p1));                  // one v_mov builds the {h,0} pair
     c = add64_32(c, __umulhi(y1, p0), k.one_b);
     const uint64_t xn = fold_product(tx, y, w, c, k);
     y = (tx << 1) + k.m - xn;                                               // tx + 4q - Q~
@@ -189,8 +188,9 @@ __device__ __forceinline__ uint64_t csub_sign_c(uint64_t x, uint64_t m, uint64_t
     return d + __builtin_bit_cast(uint64_t, add);
 }
 
-struct final_consts {   // fast form only
+struct final_consts {   // fast forms only
     uint64_t q2, nq2, q1, nq1;
+    uint64_t q8, nq8;   // 8q and its negation: the conditional-subtract step of the 16q-lazy form
 };
 
 template <bool FAST>
@@ -205,6 +205,49 @@ __device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k,
     }
 }
 
+
+// 16q-LAZY arithmetic for q <= 2^60 (16q <= 2^64): with twice the headroom of the fast form the
+// conditional subtract is only needed when the running bound would pass 16q, which is on 5 of 12
+// stages at n = 4096 (lazy16_schedule below) instead of on every stage.  A skipped stage maps a
+// bound B to B + 4q (x' = x + Q~, y' = x + 4q - Q~, Q~ < 4q); a subtracting stage uses the step 8q:
+// tx = x - [x >= 8q] 8q < max(8q, B - 8q).  Same residues as the other forms at every stage.
+struct lazy16_schedule {
+    // bound (in units of q) on the coefficients entering stage s, and whether stage s subtracts;
+    // inputs are < 4q (the reference's input range, src/kernel/ntt.cpp:331-332)
+    static constexpr int bound_in(int s) {
+        int b = 4;
+        for (int i = 0; i < s; ++i) b = next(b);
+        return b;
+    }
+    static constexpr bool subtracts(int s) { return bound_in(s) + 4 > 16; }
+    static constexpr int next(int b) { return (b + 4 > 16 ? (b - 8 > 8 ? b - 8 : 8) : b) + 4; }
+};
+
+template <bool SEL, bool DO_CSUB>
+__device__ __forceinline__ void ct_butterfly_lazy16(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k,
+                                                    const final_consts& f) {
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
+    uint64_t tx = x;
+    if constexpr (DO_CSUB) {
+        const uint64_t d = x + f.nq8;
+        if constexpr (SEL) tx = (int64_t)d < 0 ? x : d;
+        else tx = csub_sign_c(x, f.q8, f.nq8);
+    }
+    uint64_t c = mad64(p1, y1, (uint64_t)__umulhi(y0, p1));                  // one v_mov builds the {h,0} pair
+    c = add64_32(c, __umulhi(y1, p0), k.one_b);
+    const uint64_t xn = fold_product(tx, y, w, c, k);
+    y = (tx << 1) + k.m - xn;                                               // tx + 4q - Q~
+    x = xn;
+}
+
+// [0,16q) -> [0,q)
+__device__ __forceinline__ uint64_t reduce_final_lazy16(uint64_t v, const bf_consts& k, const final_consts& f) {
+    v = csub_sign_c(v, f.q8, f.nq8);
+    v = csub_sign(v, k);                 // 4q
+    v = csub_sign_c(v, f.q2, f.nq2);
+    return csub_sign_c(v, f.q1, f.nq1);
+}
+
 // w*d - c*q (mod 2^64) with the quotient estimate of the chosen arithmetic:
 // exact -> [0,2q), fast -> [0,4q); d may be any 64-bit value
 template <bool FAST>
@@ -212,8 +255,7 @@ __device__ __forceinline__ uint64_t mul_shoup_form(uint64_t d, uint64_t w, uint6
     const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
     uint64_t c;
     if constexpr (FAST) {
-        c = mul64(p1, d1);
-        c = add64_32(c, __umulhi(d0, p1), k.one_a);
+        c = mad64(p1, d1, (uint64_t)__umulhi(d0, p1));
         c = add64_32(c, __umulhi(d1, p0), k.one_b);
     } else {
         const uint32_t t = __umulhi(d0, p0);

@@ -16,6 +16,7 @@
 #include "modarith.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -355,13 +356,14 @@ __device__ __forceinline__ twpair load_uniform(const twpair* p) {
 // option bits of the second-generation kernels (A/B switches; the tuned defaults are in the registry)
 constexpr int kOptPad = 1;       // padded LDS image, exchanges addressed base + immediate offset
 constexpr int kOptSelect = 2;    // conditional subtract by compare + select instead of sign mask
+constexpr int kOptLazy16 = 16;   // q <= 2^60: 16q-lazy forward butterflies (conditional subtract on 5 of 12 stages)
 
 // per-frame state shared by the second-generation kernels
 template <int L, int R, bool FAST, int OPT = 0>
 struct rb2_frame {
     using G = rb2_geom<L, R>;
     static constexpr int C = G::C, T = G::T, NP = G::NP;
-    static constexpr bool PAD = (OPT & kOptPad) != 0, SEL = (OPT & kOptSelect) != 0;
+    static constexpr bool PAD = (OPT & kOptPad) != 0, SEL = (OPT & kOptSelect) != 0, LAZY16 = FAST && (OPT & kOptLazy16) != 0;
     static constexpr uint32_t slab_elems = PAD ? (1u << L) + (1u << (L - 4)) : (1u << L);
     // image word of coefficient e; both forms are additive over disjoint bit fields, which is what
     // lets an exchange address register r as (thread base) combined with a compile-time constant
@@ -383,6 +385,8 @@ struct rb2_frame {
         fc.nq2 = opaque_sgpr64(0 - fc.q2);
         fc.q1 = q;
         fc.nq1 = opaque_sgpr64(0 - fc.q1);
+        fc.q8 = q << 3;
+        fc.nq8 = opaque_sgpr64(0 - fc.q8);
     }
 
     // image word of (pass p, register r) for this thread
@@ -444,7 +448,7 @@ struct rb2_frame {
     // pass-0 layout); every pass but the last writes the image; `sync_first` = order the exchange
     // that precedes pass P0 (split out so a caller can put work between the write and the sync)
     template <int P0, int P1>
-    __device__ __forceinline__ void forward_passes(uint64_t (&x)[C], const twpair* tbl, bool sync_last_write) const {
+    __device__ __forceinline__ void forward_passes(uint64_t (&x)[C], const twpair* tbl) const {
         static_for<P0, P1>([&](auto P) {
             constexpr int p = P;
             constexpr int rlo = G::rlo(p), hi = G::hi(p);
@@ -464,11 +468,18 @@ struct rb2_frame {
                     constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
                     constexpr int r1 = r0 | (1 << rb);
                     const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
-                    if constexpr (FAST) ct_butterfly_fast<SEL>(x[r0], x[r1], w.x, w.y, k);
+                    constexpr int stage = L - 1 - (rlo + rb);      // 0 = first stage of the resident transform
+                    if constexpr (LAZY16) ct_butterfly_lazy16<SEL, lazy16_schedule::subtracts(stage)>(x[r0], x[r1], w.x, w.y, k, fc);
+                    else if constexpr (FAST) ct_butterfly_fast<SEL>(x[r0], x[r1], w.x, w.y, k);
                     else ct_butterfly_exact(x[r0], x[r1], w.x, w.y, k);
                     if constexpr (last_stage) {
-                        x[r0] = reduce_final<FAST>(x[r0], k, fc);
-                        x[r1] = reduce_final<FAST>(x[r1], k, fc);
+                        if constexpr (LAZY16) {
+                            x[r0] = reduce_final_lazy16(x[r0], k, fc);
+                            x[r1] = reduce_final_lazy16(x[r1], k, fc);
+                        } else {
+                            x[r0] = reduce_final<FAST>(x[r0], k, fc);
+                            x[r1] = reduce_final<FAST>(x[r1], k, fc);
+                        }
                     }
                 });
             });
@@ -479,17 +490,11 @@ struct rb2_frame {
                 if constexpr (p < P1 - 1) exchange_sync<p>();
             }
         });
-        (void)sync_last_write;
     }
     // x in pass-0 layout (element tid + T*r, any values in [0,2m)) -> forward transform, x in the
     // last pass's layout (elements tid*C .. tid*C+C-1), fully reduced
     __device__ __forceinline__ void forward(uint64_t (&x)[C], const twpair* tbl) const {
-        if constexpr (NP == 1) {
-            forward_passes<0, 1>(x, tbl, false);
-        } else {
-            forward_passes<0, 1>(x, tbl, false);
-            forward_passes<1, NP>(x, tbl, false);
-        }
+        forward_passes<0, NP>(x, tbl);
     }
 
     // x in the last pass's layout, values in [0,m) -> inverse transform (Gentleman-Sande, gap bits
@@ -688,7 +693,7 @@ struct rb_entry {
     void (*build)(const regblock_layout&, const uint64_t*, const uint64_t*, std::vector<ulonglong2>&);
     hipError_t (*launch)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     hipError_t (*init)();
-    int arith;   // 0: exact (reference op sequence, q < 2^62); 1: fast (q <= 2^61)
+    int arith;   // 0: exact (reference op sequence, q < 2^62); 1: fast (q <= 2^61); 2: 16q-lazy (q <= 2^60)
     hipError_t (*launch_inv)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     hipError_t (*launch_mul)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
 };
@@ -788,7 +793,8 @@ hipError_t init_rb2_t() {
 template <int L, int R, int PPB, int ARITH, int MINW>
 constexpr rb_entry make_entry2(int id) {
     return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, rb2_lds_bytes<L, R, PPB, ARITH>(),
-                    &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>, ARITH & 1,
+                    &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>,
+                    (ARITH & 1) ? ((((ARITH >> 1) & kOptLazy16) != 0) ? 2 : 1) : 0,
                     &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>};
 }
 
@@ -798,43 +804,40 @@ constexpr rb_entry make_entry(int id) {
                     &build_table_t<L, R>, &launch_rb_t<L, R, PPB, STAGE_OUT, MINW>, &init_rb_t<L, R, PPB, STAGE_OUT, MINW>, 0, nullptr, nullptr};
 }
 
+// ids are stable handles for tests and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices
 const rb_entry kRbEntries[] = {
+    // first generation (portable butterfly, exact): kept as the measured starting point
     make_entry<10, 4, 4, false, 1>(0),
     make_entry<11, 4, 2, false, 1>(1),
     make_entry<12, 4, 1, false, 1>(2),
     make_entry<13, 5, 1, false, 1>(3),
     make_entry<14, 5, 1, false, 1>(4),
-    // experiments at n = 4096
-    make_entry<12, 4, 1, true, 1>(5),
-    make_entry<12, 3, 1, false, 1>(6),
-    make_entry<12, 3, 1, false, 8>(7),
-    make_entry<12, 3, 1, true, 8>(8),
-    make_entry<12, 4, 1, false, 6>(9),
-    make_entry<12, 5, 2, false, 1>(10),
-    make_entry<12, 4, 1, false, 5>(11),
-    make_entry2<12, 3, 1, 1, 8>(12),   // fast arithmetic, 8 waves/SIMD, XOR-swizzled image, sign-mask csub
-    make_entry2<12, 3, 1, 0, 8>(13),   // exact arithmetic
-    make_entry2<12, 3, 1, 1, 1>(14),
-    make_entry2<12, 4, 1, 1, 1>(15),
-    make_entry2<12, 4, 1, 1, 6>(16),
-    // second generation, other sizes (fast, exact), first tuning
-    make_entry2<10, 3, 4, 1, 8>(17), make_entry2<10, 3, 4, 0, 8>(18),
-    make_entry2<11, 3, 2, 1, 8>(19), make_entry2<11, 3, 2, 0, 8>(20),
-    make_entry2<13, 3, 1, 1, 8>(21), make_entry2<13, 3, 1, 0, 8>(22),
-    make_entry2<14, 4, 1, 1, 4>(23), make_entry2<14, 4, 1, 0, 4>(24),
-    // option bits (ARITH = fast | options << 1): padded image + select-based csub measured best
-    make_entry2<12, 3, 1, 1 | (kOptPad << 1), 8>(25),
-    make_entry2<12, 3, 1, 1 | (kOptSelect << 1), 8>(26),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(27),
+    // second generation at n = 4096 as first measured: XOR-swizzled image, sign-mask csub
+    make_entry2<12, 3, 1, 1, 8>(12),
+    make_entry2<12, 3, 1, 0, 8>(13),
+    // tuned second generation: exact (padded image), fast (+ select csub), 16q-lazy (q <= 2^60)
     make_entry2<12, 3, 1, 0 | (kOptPad << 1), 8>(28),
-    make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29), make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
-    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31), make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
-    make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(33), make_entry2<13, 3, 1, 0 | (kOptPad << 1), 8>(34),
-    make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect) << 1), 4>(35), make_entry2<14, 4, 1, 0 | (kOptPad << 1), 4>(36),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(27),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(39),
+    make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
+    make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29),
+    make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(40),
+    make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
+    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31),
+    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(41),
+    make_entry2<13, 3, 1, 0 | (kOptPad << 1), 8>(34),
+    make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(33),
+    make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(42),
+    make_entry2<14, 4, 1, 0 | (kOptPad << 1), 4>(36),
+    make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect) << 1), 4>(35),
+    make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 4>(43),
 };
-constexpr int kNumRbEntries = sizeof(kRbEntries) / sizeof(kRbEntries[0]);
 
-const rb_entry* rb_lookup(int id) { return (id >= 0 && id < kNumRbEntries) ? &kRbEntries[id] : nullptr; }
+const rb_entry* rb_lookup(int id) {
+    for (const rb_entry& e : kRbEntries)
+        if (e.id == id) return &e;
+    return nullptr;
+}
 
 unsigned grid_1d(uint64_t work_items, unsigned threads) {
     uint64_t blocks = (work_items + threads - 1) / threads;
@@ -850,7 +853,7 @@ hipError_t set_lds_attr(F* fn, size_t bytes) {
 
 }  // namespace
 
-regblock_layout regblock_choose(uint32_t n, int config_id, bool allow_fast) {
+regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
     regblock_layout rb;
     int log_n = 0;
     while ((1u << log_n) < n) ++log_n;
@@ -860,13 +863,13 @@ regblock_layout regblock_choose(uint32_t n, int config_id, bool allow_fast) {
     const rb_entry* e = nullptr;
     if (config_id >= 0) {
         e = rb_lookup(config_id);
-        if (e && (e->log_local != log_local || (e->arith == 1 && !allow_fast))) e = nullptr;
+        if (e && (e->log_local != log_local || e->arith > arith_level)) e = nullptr;
     } else {
         // tuned defaults, best first; fast arithmetic only when every modulus is <= 2^61
-        static const int kDefaults[] = {27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 12, 13, 17, 18, 19, 20, 21, 22, 23, 24, 0, 1, 2, 3, 4};
+        static const int kDefaults[] = {39, 27, 28, 40, 29, 30, 41, 31, 32, 42, 33, 34, 43, 35, 36, 0, 1, 2, 3, 4};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
-            if (c && c->log_local == log_local && (c->arith == 0 || allow_fast)) { e = c; break; }
+            if (c && c->log_local == log_local && c->arith <= arith_level) { e = c; break; }
         }
     }
     if (!e) return rb;

@@ -44,8 +44,9 @@ struct frame_layout {
 
 // host-side construction of the register-blocked forward table for one prime from its
 // natural-index tables; appends rb.pairs_per_prime pairs to `out`
-// config_id -1: tuned default for n; allow_fast: every modulus is <= 2^61 (fast arithmetic legal)
-regblock_layout regblock_choose(uint32_t n, int config_id, bool allow_fast);
+// config_id -1: tuned default for n; arith_level: 0 exact only, 1 every modulus <= 2^61 (fast form legal),
+// 2 every modulus <= 2^60 (16q-lazy form legal)
+regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level);
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out);
 
 hipError_t kernels_init();  // one-time function attributes (large dynamic LDS)

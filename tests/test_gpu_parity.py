@@ -143,17 +143,19 @@ def test_structured_known_answers(agx, dev, n):
 
 
 @pytest.mark.parametrize("bits", [30, 60, 61, 62])
-@pytest.mark.parametrize("config", ["default", 2, 12, 13])
+@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39])
 def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
-    """every registered n=4096 kernel (first-generation exact, second-generation fast / exact)
-    against the oracle, for 30-, 60-, 61- and 62-bit moduli; 62-bit moduli must be refused by the
-    fast kernel and run on the exact one by default"""
+    """every registered n=4096 kernel (first-generation exact; second-generation exact, fast and
+    16q-lazy) against the oracle, for 30-, 60-, 61- and 62-bit moduli; a form whose lazy range does
+    not fit the modulus must be refused, and the default must fall back to a legal one"""
     n, batch, primes = 4096, 3, 2
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes, inverse=False)
     if config != "default":
-        if config == 12 and bits == 62:
+        # fast forms need q <= 2^61, the 16q-lazy form q <= 2^60: anything else must be refused
+        illegal = (config in (12, 27) and bits == 62) or (config == 39 and bits >= 61)
+        if illegal:
             with pytest.raises(agx.AgxError) as ei:
-                plan.set_variant(agx.VARIANT_REGBLOCK_BASE + 12)
+                plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
             assert ei.value.status == 2
             plan.close()
             return
@@ -166,15 +168,18 @@ def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     plan.close()
 
 
-def test_extreme_coefficients_fast_kernel(agx, orc, dev):
-    """worst-case lazy ranges: all coefficients 4q-1 / q-1 / 0 under the largest 61-bit modulus"""
+@pytest.mark.parametrize("bits", [60, 61, 62])
+def test_extreme_coefficients(agx, orc, dev, bits):
+    """worst-case lazy ranges: all coefficients 4q-1 / q-1 / 0 under the largest 60-, 61- and
+    62-bit moduli (16q-lazy, fast and exact forms respectively)"""
     n = 4096
-    q = orc.find_prime(61, n)
+    q = orc.find_prime(bits, n)
     psi = orc.min_root(q, n)
     tw, pre = orc.make_tables(q, psi, n)
     plan = agx.Plan(n, [q], psi=[psi])
-    x = np.concatenate([np.full(n, 4 * q - 1, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64),
-                        np.where(np.arange(n) % 2 == 0, np.uint64(4 * q - 1), np.uint64(0))])
+    top = min(4 * q - 1, 2**64 - 1)
+    x = np.concatenate([np.full(n, top, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64),
+                        np.where(np.arange(n) % 2 == 0, np.uint64(top), np.uint64(0))])
     d = dev.to_device(x)
     plan.forward(d.data_ptr(), d.data_ptr(), 4, dev.stream)
     assert np.array_equal(dev.to_host(d), orc.forward(x, q, tw, pre, n))
