@@ -28,6 +28,8 @@ struct agx_ntt_plan {
     ulonglong2* d_tw_rb = nullptr;
     ulonglong2* d_itw_rb = nullptr;
     regblock_layout rb;
+    regblock_layout rb_oop;            // forward layout used when out != in (fused-split kernels), or invalid
+    ulonglong2* d_tw_rb_oop = nullptr;
 };
 
 namespace {
@@ -77,6 +79,7 @@ void free_plan(agx_ntt_plan* p) {
     if (p->d_itw) (void)hipFree(p->d_itw);
     if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
     if (p->d_itw_rb) (void)hipFree(p->d_itw_rb);
+    if (p->d_tw_rb_oop) (void)hipFree(p->d_tw_rb_oop);
     delete p;
 }
 
@@ -131,7 +134,8 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         }
     }
     p->rb = regblock_choose(n, -1, p->arith_level);
-    std::vector<ulonglong2> rb_pairs, irb_pairs;
+    p->rb_oop = regblock_choose_out_of_place(n, p->arith_level);
+    std::vector<ulonglong2> rb_pairs, irb_pairs, oop_pairs;
     for (uint32_t k = 0; k < num_primes; ++k) {
         const uint64_t q = moduli[k];
         prime_consts& c = consts[k];
@@ -154,12 +158,14 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
             if (p->rb.valid()) regblock_build_table(p->rb, itwk, iprek, irb_pairs);
         }
         if (p->rb.valid()) regblock_build_table(p->rb, twk, prek, rb_pairs);
+        if (p->rb_oop.valid()) regblock_build_table(p->rb_oop, twk, prek, oop_pairs);
     }
     if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
     if ((rc = upload(&p->d_tw, tw_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (itw && (rc = upload(&p->d_itw, itw_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && (rc = upload(&p->d_tw_rb, rb_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && itw && (rc = upload(&p->d_itw_rb, irb_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (p->rb_oop.valid() && (rc = upload(&p->d_tw_rb_oop, oop_pairs)) != AGX_OK) { free_plan(p); return rc; }
     *out = p;
     return AGX_OK;
 }
@@ -281,6 +287,12 @@ int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant) {
             plan->rb = rb;
         }
     }
+    if (config_id >= 0) {
+        plan->rb_oop = regblock_layout{};            // an explicit kernel choice applies to every call
+    } else if (!plan->rb_oop.valid() && variant != AGX_VARIANT_LDS_RADIX2) {
+        const regblock_layout oop = regblock_choose_out_of_place(plan->n, plan->arith_level);
+        if (oop.valid() && plan->d_tw_rb_oop) plan->rb_oop = oop;   // tables were built at creation
+    }
     plan->variant = variant;
     return AGX_OK;
 }
@@ -308,8 +320,12 @@ int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint
     if (rc) return rc;
     if (batch == 0) return AGX_OK;
     const frame_layout fl{batch, prime_stride, poly_stride};
-    const plan_view pv = view_of(plan);
+    plan_view pv = view_of(plan);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d_in != d_out && plan->rb_oop.valid() && plan->variant != AGX_VARIANT_LDS_RADIX2) {
+        pv.rb = plan->rb_oop;
+        pv.tw_rb = plan->d_tw_rb_oop;
+    }
     AGX_HIP(use_regblock(plan) ? launch_forward_regblock(pv, d_in, d_out, fl, s) : launch_forward_radix2(pv, d_in, d_out, fl, s));
     return AGX_OK;
 }

@@ -359,7 +359,7 @@ constexpr int kOptSelect = 2;    // conditional subtract by compare + select ins
 constexpr int kOptLazy16 = 16;   // q <= 2^60: 16q-lazy forward butterflies (conditional subtract on 5 of 12 stages)
 
 // per-frame state shared by the second-generation kernels
-template <int L, int R, bool FAST, int OPT = 0>
+template <int L, int R, bool FAST, int OPT = 0, int S0 = 0>   // S0: stages already done before the resident transform
 struct rb2_frame {
     using G = rb2_geom<L, R>;
     static constexpr int C = G::C, T = G::T, NP = G::NP;
@@ -387,6 +387,14 @@ struct rb2_frame {
         fc.nq1 = opaque_sgpr64(0 - fc.q1);
         fc.q8 = q << 3;
         fc.nq8 = opaque_sgpr64(0 - fc.q8);
+    }
+
+    // forward butterfly number `stage` of the whole transform in this frame's arithmetic
+    template <int stage>
+    __device__ __forceinline__ void butterfly(uint64_t& a, uint64_t& b, const twpair& w) const {
+        if constexpr (LAZY16) ct_butterfly_lazy16<SEL, lazy16_schedule::subtracts(stage)>(a, b, w.x, w.y, k, fc);
+        else if constexpr (FAST) ct_butterfly_fast<SEL>(a, b, w.x, w.y, k);
+        else ct_butterfly_exact(a, b, w.x, w.y, k);
     }
 
     // image word of (pass p, register r) for this thread
@@ -468,10 +476,8 @@ struct rb2_frame {
                     constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
                     constexpr int r1 = r0 | (1 << rb);
                     const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
-                    constexpr int stage = L - 1 - (rlo + rb);      // 0 = first stage of the resident transform
-                    if constexpr (LAZY16) ct_butterfly_lazy16<SEL, lazy16_schedule::subtracts(stage)>(x[r0], x[r1], w.x, w.y, k, fc);
-                    else if constexpr (FAST) ct_butterfly_fast<SEL>(x[r0], x[r1], w.x, w.y, k);
-                    else ct_butterfly_exact(x[r0], x[r1], w.x, w.y, k);
+                    constexpr int stage = S0 + L - 1 - (rlo + rb);   // position in the whole transform
+                    butterfly<stage>(x[r0], x[r1], w);
                     if constexpr (last_stage) {
                         if constexpr (LAZY16) {
                             x[r0] = reduce_final_lazy16(x[r0], k, fc);
@@ -593,6 +599,67 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     f.store_last_layout(x, out, base, live);
 }
 
+// Forward transform of frames of 2^(L+S) coefficients by workgroups that keep 2^L of them: block
+// `blk` of a frame computes the S leading stages for its own contiguous 2^L outputs straight from
+// global memory (reading the 2^S strided partners of each coefficient, so those stages' multiplies
+// are done 2^S-1 times over) and then runs the resident transform.  Against a separate pass for the
+// leading stages this saves 16n bytes of HBM traffic per stage and keeps the 64 KiB-per-frame
+// occupancy (8 waves/SIMD) for n = 16384 and 32768.  NOT safe in place: every block reads the whole
+// frame, so the host only selects it when out != in.
+template <int L, int R, int PPB, int ARITH, int MINW, int S>
+__global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
+fwd_rb2_split(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+              const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_nat, const twpair* __restrict__ tw_rb,
+              uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride) {
+    static_assert(S == 1 || S == 2, "one or two leading stages");
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1), S>;
+    constexpr int C = F::C, T = F::T;
+    constexpr uint32_t split_log = S;
+    F f;
+    f.tid = threadIdx.x & (T - 1);
+    const uint32_t slot = threadIdx.x / T;
+    uint64_t fx = (uint64_t)blockIdx.x * PPB + slot;
+    const bool live = fx < frames_x;
+    if (!live) fx = frames_x - 1;
+    const uint32_t prime = blockIdx.y;
+    const uint64_t poly = fx >> split_log;
+    f.blk = (uint32_t)(fx & ((1u << split_log) - 1u));
+    f.split_log = split_log;
+    f.init_consts(consts[prime].q);
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds) + (size_t)slot * F::slab_elems;
+    const int64_t frame = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
+    const int64_t base = frame + ((int64_t)f.blk << L);
+    const twpair* nat = tw_nat + ((size_t)prime << (L + S));
+    const uint32_t blk = f.blk;     // wave-uniform
+
+    uint64_t x[C];
+    if constexpr (S == 1) {
+        const twpair w1 = load_uniform(nat + 1);
+        static_for<0, C>([&](auto Rr) {
+            constexpr int r = Rr;
+            const int64_t e = frame + f.tid + (uint32_t)r * T;
+            uint64_t a = in[e], b = in[e + (1 << L)];
+            f.template butterfly<0>(a, b, w1);
+            x[r] = blk ? b : a;
+        });
+    } else {
+        const twpair w1 = load_uniform(nat + 1), w2 = load_uniform(nat + 2 + (blk >> 1));
+        static_for<0, C>([&](auto Rr) {
+            constexpr int r = Rr;
+            // this block's half of the frame after stage 0 needs both stage-0 partners of its two quarters
+            uint64_t lo0 = in[frame + f.tid + (uint32_t)r * T], hi0 = in[frame + f.tid + (uint32_t)r * T + (2 << L)];
+            uint64_t lo1 = in[frame + f.tid + (uint32_t)r * T + (1 << L)], hi1 = in[frame + f.tid + (uint32_t)r * T + (3 << L)];
+            f.template butterfly<0>(lo0, hi0, w1);
+            f.template butterfly<0>(lo1, hi1, w1);
+            uint64_t p = (blk >> 1) ? hi0 : lo0, q = (blk >> 1) ? hi1 : lo1;
+            f.template butterfly<1>(p, q, w2);
+            x[r] = (blk & 1) ? q : p;
+        });
+    }
+    f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
+    f.store_last_layout(x, out, base, live);
+}
+
 template <int L, int R, int PPB, int ARITH, int MINW>
 __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 inv_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
@@ -696,6 +763,8 @@ struct rb_entry {
     int arith;   // 0: exact (reference op sequence, q < 2^62); 1: fast (q <= 2^61); 2: 16q-lazy (q <= 2^60)
     hipError_t (*launch_inv)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     hipError_t (*launch_mul)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    int fused_split;   // S > 0: `launch` is only for out != in and computes the S leading stages itself (n = 2^(log_local+S))
+    hipError_t (*launch_fused)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
 };
 
 template <int L, int R, bool col_major = false>
@@ -795,13 +864,44 @@ constexpr rb_entry make_entry2(int id) {
     return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, rb2_lds_bytes<L, R, PPB, ARITH>(),
                     &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>,
                     (ARITH & 1) ? ((((ARITH >> 1) & kOptLazy16) != 0) ? 2 : 1) : 0,
-                    &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>};
+                    &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>, 0, nullptr};
+}
+
+template <int L, int R, int PPB, int ARITH, int MINW, int S>
+hipError_t launch_rb2_split_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    const uint64_t frames_x = fl.batch << S;
+    const size_t lds = rb2_lds_bytes<L, R, PPB, ARITH>();
+    dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
+    hipLaunchKernelGGL((fwd_rb2_split<L, R, PPB, ARITH, MINW, S>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts, pv.tw, pv.tw_rb,
+                       pv.rb.pairs_per_prime, frames_x, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
+template <int L, int R, int PPB, int ARITH, int MINW, int S>
+hipError_t init_rb2_split_t() {
+    hipError_t e = init_rb2_t<L, R, PPB, ARITH, MINW>();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_split<L, R, PPB, ARITH, MINW, S>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb2_lds_bytes<L, R, PPB, ARITH>());
+    return e;
+}
+
+// a second-generation entry for n = 2^(L+S): resident blocks of 2^L, leading S stages fused into the
+// forward kernel when out != in (in place they run as separate fwd_global_stage passes)
+template <int L, int R, int PPB, int ARITH, int MINW, int S>
+constexpr rb_entry make_entry_split(int id) {
+    rb_entry e = make_entry2<L, R, PPB, ARITH, MINW>(id);
+    e.init = &init_rb2_split_t<L, R, PPB, ARITH, MINW, S>;
+    e.fused_split = S;
+    e.launch_fused = &launch_rb2_split_t<L, R, PPB, ARITH, MINW, S>;
+    return e;
 }
 
 template <int L, int R, int PPB, bool STAGE_OUT, int MINW>
 constexpr rb_entry make_entry(int id) {
     return rb_entry{id, L, R, PPB, STAGE_OUT, MINW, (uint32_t)rb_geom<L, R>::table_pairs, (size_t)rb_geom<L, R>::lds_elems * 8 * PPB,
-                    &build_table_t<L, R>, &launch_rb_t<L, R, PPB, STAGE_OUT, MINW>, &init_rb_t<L, R, PPB, STAGE_OUT, MINW>, 0, nullptr, nullptr};
+                    &build_table_t<L, R>, &launch_rb_t<L, R, PPB, STAGE_OUT, MINW>, &init_rb_t<L, R, PPB, STAGE_OUT, MINW>, 0, nullptr, nullptr, 0, nullptr};
 }
 
 // ids are stable handles for tests and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices
@@ -831,6 +931,13 @@ const rb_entry kRbEntries[] = {
     make_entry2<14, 4, 1, 0 | (kOptPad << 1), 4>(36),
     make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect) << 1), 4>(35),
     make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 4>(43),
+    // n = 16384 / 32768 as 2 / 4 resident blocks of 8192 (8 waves/SIMD) with fused leading stages
+    make_entry_split<13, 3, 1, 0 | (kOptPad << 1), 8, 1>(44),
+    make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8, 1>(45),
+    make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8, 1>(46),
+    make_entry_split<13, 3, 1, 0 | (kOptPad << 1), 8, 2>(47),
+    make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8, 2>(48),
+    make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8, 2>(49),
 };
 
 const rb_entry* rb_lookup(int id) {
@@ -858,28 +965,43 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
     int log_n = 0;
     while ((1u << log_n) < n) ++log_n;
     if (log_n < 10) return rb;  // small sizes stay on the radix-2 kernel
-    const int log_split = log_n > kMaxLdsLog ? log_n - kMaxLdsLog : 0;
-    const int log_local = log_n - log_split;
+    // an entry serves n if its resident size plus its (fixed or default) number of split stages is log_n
+    auto split_for = [&](const rb_entry& e) -> int {
+        if (e.fused_split > 0) return e.log_local + e.fused_split == log_n ? e.fused_split : -1;
+        const int split = log_n > kMaxLdsLog ? log_n - kMaxLdsLog : 0;
+        return e.log_local + split == log_n ? split : -1;
+    };
     const rb_entry* e = nullptr;
     if (config_id >= 0) {
         e = rb_lookup(config_id);
-        if (e && (e->log_local != log_local || e->arith > arith_level)) e = nullptr;
+        if (e && (split_for(*e) < 0 || e->arith > arith_level)) e = nullptr;
     } else {
-        // tuned defaults, best first; fast arithmetic only when every modulus is <= 2^61
+        // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
         static const int kDefaults[] = {39, 27, 28, 40, 29, 30, 41, 31, 32, 42, 33, 34, 43, 35, 36, 0, 1, 2, 3, 4};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
-            if (c && c->log_local == log_local && c->arith <= arith_level) { e = c; break; }
+            if (c && split_for(*c) >= 0 && c->arith <= arith_level) { e = c; break; }
         }
     }
     if (!e) return rb;
     rb.config_id = e->id;
     rb.log_n = log_n;
-    rb.log_split = log_split;
-    rb.log_local = log_local;
+    rb.log_split = split_for(*e);
+    rb.log_local = e->log_local;
     rb.r = e->r;
-    rb.pairs_per_prime = e->table_pairs << log_split;
+    rb.pairs_per_prime = e->table_pairs << rb.log_split;
     return rb;
+}
+
+// tuned configuration for out-of-place forward calls, where a fused-split kernel may read the whole
+// frame from every block; invalid layout when n has none
+regblock_layout regblock_choose_out_of_place(uint32_t n, int arith_level) {
+    static const int kOop[] = {46, 45, 44, 49, 48, 47};
+    for (int id : kOop) {
+        regblock_layout rb = regblock_choose(n, id, arith_level);
+        if (rb.valid()) return rb;
+    }
+    return regblock_layout{};
 }
 
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {
@@ -936,6 +1058,9 @@ hipError_t launch_inverse_radix2(const plan_view& pv, const uint64_t* in, uint64
 
 hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     if (!pv.rb.valid()) return hipErrorInvalidValue;
+    const rb_entry* e = rb_lookup(pv.rb.config_id);
+    if (!e) return hipErrorInvalidValue;
+    if (e->fused_split > 0 && in != out) return e->launch_fused(pv, in, out, fl, s);   // every block reads the whole frame
     const uint64_t* src = in;
     for (int st = 0; st < pv.rb.log_split; ++st) {
         dim3 grid(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);
@@ -943,9 +1068,7 @@ hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint
                            fl.prime_stride, fl.poly_stride);
         src = out;
     }
-    const rb_entry* e = rb_lookup(pv.rb.config_id);
-    if (e) return e->launch(pv, src, out, fl, s);
-    return hipErrorInvalidValue;
+    return e->launch(pv, src, out, fl, s);
 }
 
 bool regblock_has_inverse(const regblock_layout& rb) {

@@ -22,6 +22,7 @@ ap.add_argument("--primes", type=int, default=4)
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--slabs", type=int, default=4)
 ap.add_argument("--op", choices=["fwd", "inv", "mul"], default="fwd")
+ap.add_argument("--oop", action="store_true", help="time out of place (slab i -> slab i+1) instead of in place")
 args = ap.parse_args()
 N, P, B, SLABS = args.n, args.primes, args.batch, args.slabs
 ids = args.ids or [2, 5, 6, 7, 8, 9, 10, 11]
@@ -67,11 +68,11 @@ for rnd in range(5):
     for k in ids:
         select(k)
         for i in range(3):
-            run(slabs[i % SLABS], slabs[i % SLABS], slabs[(i + 1) % SLABS])
+            run(slabs[i % SLABS], slabs[(i + 1) % SLABS] if args.oop else slabs[i % SLABS], slabs[(i + 1) % SLABS])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(20):
-            run(slabs[i % SLABS], slabs[i % SLABS], slabs[(i + 1) % SLABS])
+            run(slabs[i % SLABS], slabs[(i + 1) % SLABS] if args.oop else slabs[i % SLABS], slabs[(i + 1) % SLABS])
         e1.record()
         torch.cuda.synchronize()
         times[k].append(e0.elapsed_time(e1) / 20)
