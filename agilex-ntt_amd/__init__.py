@@ -33,6 +33,7 @@ ABI = {
     "agx_ntt_last_hip_error": (_int, []),
     "agx_ntt_device_count": (_int, [ctypes.POINTER(_int)]),
     "agx_ntt_forward_host": (_int, [_p64, _p64, _p64, _p64, _p64, _p64, _u32, _u32]),
+    "agx_ntt_forward_host_stream": (_int, [_vp, _p64, _p64, _p64, _u64]),
     "agx_ntt_plan_create": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64, _p64, _p64, _p64]),
     "agx_ntt_plan_create_auto": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64]),
     "agx_ntt_plan_destroy": (_int, [_vp]),
@@ -40,6 +41,7 @@ ABI = {
     "agx_ntt_plan_info": (_int, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "agx_ntt_plan_get_modulus": (_int, [_vp, _u32, _p64, _p64]),
     "agx_ntt_forward": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "agx_ntt_forward_lazy": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "agx_ntt_inverse": (_int, [_vp, _vp, _vp, _u64, _vp]),
     "agx_ntt_forward_strided": (_int, [_vp, _vp, _vp, _u64, _i64, _i64, _vp]),
     "agx_ntt_inverse_strided": (_int, [_vp, _vp, _vp, _u64, _i64, _i64, _vp]),
@@ -204,6 +206,9 @@ class Plan:
     def forward(self, d_in, d_out, batch, stream=0):
         _check(lib().agx_ntt_forward(self._h, d_in, d_out, batch, stream), "forward")
 
+    def forward_lazy(self, d_in, d_out, batch, stream=0):
+        _check(lib().agx_ntt_forward_lazy(self._h, d_in, d_out, batch, stream), "forward_lazy")
+
     def inverse(self, d_in, d_out, batch, stream=0):
         _check(lib().agx_ntt_inverse(self._h, d_in, d_out, batch, stream), "inverse")
 
@@ -221,6 +226,14 @@ class Plan:
 
     def fill_synthetic(self, d_out, batch, first_poly=0, seed=42, stream=0):
         _check(lib().agx_ntt_fill_synthetic(self._h, d_out, batch, first_poly, seed, stream), "fill_synthetic")
+
+    def forward_host_stream(self, in1, in2, num_frames):
+        """host frames through this (single-modulus) plan with overlapped transfers"""
+        import numpy as np
+
+        out = np.zeros(num_frames * self.n, dtype=np.uint64)
+        _check(lib().agx_ntt_forward_host_stream(self._h, _np_ptr(in1), _np_ptr(in2), _np_ptr(out), num_frames), "forward_host_stream")
+        return out
 
     def close(self):
         if self._h:

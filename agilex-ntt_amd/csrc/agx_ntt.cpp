@@ -314,12 +314,13 @@ int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uin
     return AGX_OK;
 }
 
-int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
-                            int64_t prime_stride, int64_t poly_stride, void* stream) {
+static int forward_common(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
+                          int64_t prime_stride, int64_t poly_stride, bool lazy_out, void* stream) {
     int rc = check_call(plan, d_in, d_out, batch, prime_stride, poly_stride);
     if (rc) return rc;
     if (batch == 0) return AGX_OK;
-    const frame_layout fl{batch, prime_stride, poly_stride};
+    frame_layout fl{batch, prime_stride, poly_stride};
+    fl.lazy_out = lazy_out;
     plan_view pv = view_of(plan);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d_in != d_out && plan->rb_oop.valid() && plan->variant != AGX_VARIANT_LDS_RADIX2) {
@@ -328,6 +329,16 @@ int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint
     }
     AGX_HIP(use_regblock(plan) ? launch_forward_regblock(pv, d_in, d_out, fl, s) : launch_forward_radix2(pv, d_in, d_out, fl, s));
     return AGX_OK;
+}
+
+int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
+                            int64_t prime_stride, int64_t poly_stride, void* stream) {
+    return forward_common(plan, d_in, d_out, batch, prime_stride, poly_stride, false, stream);
+}
+
+int agx_ntt_forward_lazy(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream) {
+    if (!plan) return AGX_ERR_NULL_POINTER;
+    return forward_common(plan, d_in, d_out, batch, (int64_t)(batch * plan->n), (int64_t)plan->n, true, stream);
 }
 
 int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
@@ -390,6 +401,73 @@ int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t b
     return AGX_OK;
 }
 
+// Host-resident frames through a device plan with transfers and compute overlapped: the GPU
+// analogue of the reference's streaming ntt_input_kernel / ntt_output_kernel pair
+// (src/kernel/ntt.cpp:508-640).  Three slots of pinned staging + device memory rotate over three
+// streams: while slot k computes, slot k+1 uploads and the host thread assembles slot k+2
+// (lower half of each frame from `in`, upper half from `in2`, src/kernel/ntt.cpp:584-590).
+int agx_ntt_forward_host_stream(const agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2, uint64_t* out,
+                                uint64_t num_frames) {
+    if (!plan || !in || !in2 || !out) return AGX_ERR_NULL_POINTER;
+    if (plan->num_primes != 1) return AGX_ERR_BAD_ARGUMENT;   // one modulus per stream, as the reference (ntt.cpp:143-144)
+    if (num_frames == 0) return AGX_OK;
+    const size_t n = plan->n, row = n * sizeof(uint64_t), half = row / 2;
+    constexpr int kSlots = 3;
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(num_frames, ((size_t)32 << 20) / row));
+    const uint64_t nchunks = (num_frames + chunk - 1) / chunk;
+    const int slots = (int)std::min<uint64_t>(kSlots, nchunks);
+    uint64_t *pin_in[kSlots] = {}, *pin_out[kSlots] = {}, *dev[kSlots] = {};
+    hipStream_t st[kSlots] = {};
+    hipEvent_t done[kSlots] = {};
+    hipError_t e = hipSuccess;
+    int rc = AGX_OK;
+    for (int k = 0; k < slots && e == hipSuccess; ++k) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&pin_in[k]), chunk * row, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pin_out[k]), chunk * row, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dev[k]), chunk * row);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+    }
+    auto frames_of = [&](uint64_t c) { return std::min<uint64_t>(chunk, num_frames - c * chunk); };
+    auto drain = [&](uint64_t c) {   // chunk c's results: pinned -> caller's buffer (ntt.cpp:628-633)
+        const int k = (int)(c % slots);
+        hipError_t de = hipEventSynchronize(done[k]);
+        if (de == hipSuccess) std::memcpy(out + c * chunk * n, pin_out[k], frames_of(c) * row);
+        return de;
+    };
+    for (uint64_t c = 0; c < nchunks && e == hipSuccess && rc == AGX_OK; ++c) {
+        const int k = (int)(c % slots);
+        if (c >= (uint64_t)slots) e = drain(c - slots);
+        if (e != hipSuccess) break;
+        const uint64_t f = frames_of(c);
+        const uint64_t* a = in + c * chunk * n;
+        const uint64_t* b = in2 + c * chunk * n;
+        if (a == b) {
+            std::memcpy(pin_in[k], a, f * row);
+        } else {
+            for (uint64_t i = 0; i < f; ++i) {
+                std::memcpy(reinterpret_cast<char*>(pin_in[k]) + i * row, reinterpret_cast<const char*>(a) + i * row, half);
+                std::memcpy(reinterpret_cast<char*>(pin_in[k]) + i * row + half, reinterpret_cast<const char*>(b) + i * row + half, half);
+            }
+        }
+        e = hipMemcpyAsync(dev[k], pin_in[k], f * row, hipMemcpyHostToDevice, st[k]);
+        if (e == hipSuccess) rc = agx_ntt_forward(plan, dev[k], dev[k], f, st[k]);
+        if (e == hipSuccess && rc == AGX_OK) e = hipMemcpyAsync(pin_out[k], dev[k], f * row, hipMemcpyDeviceToHost, st[k]);
+        if (e == hipSuccess && rc == AGX_OK) e = hipEventRecord(done[k], st[k]);
+    }
+    for (uint64_t c = nchunks > (uint64_t)slots ? nchunks - slots : 0; c < nchunks && e == hipSuccess && rc == AGX_OK; ++c) e = drain(c);
+    for (int k = 0; k < slots; ++k) {
+        if (st[k]) (void)hipStreamSynchronize(st[k]);
+        if (done[k]) (void)hipEventDestroy(done[k]);
+        if (st[k]) (void)hipStreamDestroy(st[k]);
+        if (dev[k]) (void)hipFree(dev[k]);
+        if (pin_in[k]) (void)hipHostFree(pin_in[k]);
+        if (pin_out[k]) (void)hipHostFree(pin_out[k]);
+    }
+    if (rc != AGX_OK) return rc;
+    return e == hipSuccess ? AGX_OK : hip_fail(e);
+}
+
 int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
                          const uint64_t* twiddles, const uint64_t* precons, uint64_t* out,
                          uint32_t n, uint32_t num_frames) {
@@ -400,21 +478,9 @@ int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t
     if (num_frames == 0) return AGX_OK;
     agx_ntt_plan* plan = nullptr;
     if ((rc = build_plan(&plan, n, 1, modulus, nullptr, twiddles, precons, nullptr, nullptr))) return rc;
-    uint64_t* d = nullptr;
-    const size_t row = (size_t)n * sizeof(uint64_t), half = row / 2;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), row * num_frames);
-    // frame b = in[b*n .. +n/2) || in2[b*n + n/2 .. +n/2)      (src/kernel/ntt.cpp:584-590)
-    if (e == hipSuccess) e = hipMemcpy2D(d, row, in, row, half, num_frames, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy2D(reinterpret_cast<char*>(d) + half, row, reinterpret_cast<const char*>(in2) + half, row, half, num_frames, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = agx_ntt_forward(plan, d, d, num_frames, nullptr);
-        if (rc == AGX_OK) e = hipMemcpy(out, d, row * num_frames, hipMemcpyDeviceToHost);  // src/kernel/ntt.cpp:628-633
-    }
-    if (d) (void)hipFree(d);
+    rc = agx_ntt_forward_host_stream(plan, in, in2, out, num_frames);
     free_plan(plan);
-    if (rc) return rc;
-    if (e != hipSuccess) return hip_fail(e);
-    return AGX_OK;
+    return rc;
 }
 
 int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t* primes_out) {

@@ -194,12 +194,14 @@ struct final_consts {   // fast forms only
 };
 
 template <bool FAST>
-__device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k, const final_consts& f) {
+__device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k, const final_consts& f, bool lazy_out = false) {
     if constexpr (FAST) {
         v = csub_sign(v, k);                 // [0,8q) -> [0,4q)
+        if (lazy_out) return v;
         v = csub_sign_c(v, f.q2, f.nq2);     // -> [0,2q)
         return csub_sign_c(v, f.q1, f.nq1);  // -> [0,q)
     } else {
+        if (lazy_out) return v;              // already in [0,4q)
         v = csub(v, k.q << 1);
         return csub(v, k.q);
     }
@@ -240,10 +242,11 @@ __device__ __forceinline__ void ct_butterfly_lazy16(uint64_t& x, uint64_t& y, ui
     x = xn;
 }
 
-// [0,16q) -> [0,q)
-__device__ __forceinline__ uint64_t reduce_final_lazy16(uint64_t v, const bf_consts& k, const final_consts& f) {
+// [0,16q) -> [0,q), or only to [0,4q) when the caller asked for lazy outputs
+__device__ __forceinline__ uint64_t reduce_final_lazy16(uint64_t v, const bf_consts& k, const final_consts& f, bool lazy_out) {
     v = csub_sign_c(v, f.q8, f.nq8);
     v = csub_sign(v, k);                 // 4q
+    if (lazy_out) return v;
     v = csub_sign_c(v, f.q2, f.nq2);
     return csub_sign_c(v, f.q1, f.nq1);
 }

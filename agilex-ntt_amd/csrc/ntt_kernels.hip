@@ -370,6 +370,7 @@ struct rb2_frame {
     static __device__ __forceinline__ constexpr uint32_t img(uint32_t e) { return PAD ? e + (e >> 4) : lds_swz(e); }
     static __device__ __forceinline__ constexpr uint32_t join(uint32_t base, uint32_t delta) { return PAD ? base + delta : base ^ delta; }
     uint32_t tid, blk, split_log;
+    bool lazy_out = false;   // forward only: leave results in [0,4q) (wave-uniform)
     uint64_t* slab;
     bf_consts k;
     final_consts fc;
@@ -480,11 +481,11 @@ struct rb2_frame {
                     butterfly<stage>(x[r0], x[r1], w);
                     if constexpr (last_stage) {
                         if constexpr (LAZY16) {
-                            x[r0] = reduce_final_lazy16(x[r0], k, fc);
-                            x[r1] = reduce_final_lazy16(x[r1], k, fc);
+                            x[r0] = reduce_final_lazy16(x[r0], k, fc, lazy_out);
+                            x[r1] = reduce_final_lazy16(x[r1], k, fc, lazy_out);
                         } else {
-                            x[r0] = reduce_final<FAST>(x[r0], k, fc);
-                            x[r1] = reduce_final<FAST>(x[r1], k, fc);
+                            x[r0] = reduce_final<FAST>(x[r0], k, fc, lazy_out);
+                            x[r1] = reduce_final<FAST>(x[r1], k, fc, lazy_out);
                         }
                     }
                 });
@@ -590,8 +591,9 @@ __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
         const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
         uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
-        int64_t prime_stride, int64_t poly_stride) {
+        int64_t prime_stride, int64_t poly_stride, uint32_t lazy_out) {
     AGX_RB2_PROLOGUE;
+    f.lazy_out = lazy_out != 0;
     uint64_t x[C];
 #pragma unroll
     for (int r = 0; r < C; ++r) x[r] = in[base + f.tid + (uint32_t)r * T];
@@ -610,7 +612,7 @@ template <int L, int R, int PPB, int ARITH, int MINW, int S>
 __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 fwd_rb2_split(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
               const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_nat, const twpair* __restrict__ tw_rb,
-              uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride) {
+              uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride, uint32_t lazy_out) {
     static_assert(S == 1 || S == 2, "one or two leading stages");
     using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1), S>;
     constexpr int C = F::C, T = F::T;
@@ -625,6 +627,7 @@ fwd_rb2_split(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     const uint64_t poly = fx >> split_log;
     f.blk = (uint32_t)(fx & ((1u << split_log) - 1u));
     f.split_log = split_log;
+    f.lazy_out = lazy_out != 0;
     f.init_consts(consts[prime].q);
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds) + (size_t)slot * F::slab_elems;
     const int64_t frame = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
@@ -824,7 +827,8 @@ hipError_t launch_rb2_t(const plan_view& pv, const uint64_t* in, uint64_t* out, 
     const size_t lds = rb2_lds_bytes<L, R, PPB, ARITH>();
     dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
     hipLaunchKernelGGL((fwd_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts, pv.tw_rb,
-                       pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride);
+                       pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride,
+                       (uint32_t)(fl.lazy_out ? 1 : 0));
     return hipGetLastError();
 }
 
@@ -874,7 +878,7 @@ hipError_t launch_rb2_split_t(const plan_view& pv, const uint64_t* in, uint64_t*
     const size_t lds = rb2_lds_bytes<L, R, PPB, ARITH>();
     dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
     hipLaunchKernelGGL((fwd_rb2_split<L, R, PPB, ARITH, MINW, S>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts, pv.tw, pv.tw_rb,
-                       pv.rb.pairs_per_prime, frames_x, fl.prime_stride, fl.poly_stride);
+                       pv.rb.pairs_per_prime, frames_x, fl.prime_stride, fl.poly_stride, (uint32_t)(fl.lazy_out ? 1 : 0));
     return hipGetLastError();
 }
 

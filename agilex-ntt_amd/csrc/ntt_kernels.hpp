@@ -40,6 +40,7 @@ struct plan_view {
 struct frame_layout {
     uint64_t batch;
     int64_t prime_stride, poly_stride;  // in elements
+    bool lazy_out = false;              // forward: results may stay in [0,4q) (kernels are free to reduce fully)
 };
 
 // host-side construction of the register-blocked forward table for one prime from its

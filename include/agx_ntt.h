@@ -70,6 +70,14 @@ int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t
                          const uint64_t* twiddles, const uint64_t* precons, uint64_t* out,
                          uint32_t n, uint32_t num_frames);
 
+/* The same path for repeated calls and large inputs: tables stay on the device in `plan` (one modulus) */
+/* and host frames stream through pinned staging buffers with upload, transform and download          */
+/* overlapped on three HIP streams (the reference streams frames through its input/output kernels,    */
+/* src/kernel/ntt.cpp:508-640).  agx_ntt_forward_host is this call on a temporary plan.                */
+struct agx_ntt_plan;
+int agx_ntt_forward_host_stream(const struct agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2,
+                                uint64_t* out, uint64_t num_frames);
+
 /* ------------------------------------------------------------------------- */
 /* (2) Plans: device-resident tables for num_primes moduli of one size n.      */
 /* A plan is immutable after creation and may be shared between host threads;  */
@@ -102,6 +110,10 @@ int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uin
 /* ------------------------------------------------------------------------- */
 int agx_ntt_forward(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
 int agx_ntt_inverse(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
+/* forward with HEXL-style lazy outputs: results are congruent to the transform and lie in [0,4q)
+ * (the last two conditional subtracts of src/kernel/ntt.cpp:377-394 are skipped where that saves
+ * work); agx_ntt_inverse, agx_ntt_pointwise and agx_ntt_forward all accept such values as inputs */
+int agx_ntt_forward_lazy(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
 int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
                             int64_t prime_stride, int64_t poly_stride, void* stream);
 int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,

@@ -110,6 +110,30 @@ def test_one_shot_host_call(agx, orc, n, bits, frames):
     assert np.array_equal(got_same, orc.forward(a, q, tw, pre, n))
 
 
+def test_host_streaming_pipeline(agx, orc):
+    """more frames than one staging chunk (32 MiB): chunks rotate over three slots/streams; in2
+    supplies the upper halves; result identical to the oracle frame for frame"""
+    n, frames = 4096, 2600                      # 81 MiB of frames -> 3 chunks (1024, 1024, 552)
+    q = agx.find_primes(60, n)[0]
+    plan = agx.Plan(n, [q])
+    tw, pre = orc.make_tables(q, plan.psi(0), n)
+    rng = np.random.default_rng(123)
+    a = rand_coeffs(rng, frames * n, q)
+    b = rand_coeffs(rng, frames * n, q)
+    got = plan.forward_host_stream(a, b, frames)
+    want = orc.forward_mt(np.concatenate([np.concatenate([a[f * n:f * n + n // 2], b[f * n + n // 2:(f + 1) * n]]) for f in range(frames)]),
+                          q, tw, pre, n, 8)
+    assert np.array_equal(got, want)
+    same = plan.forward_host_stream(a, a, frames)
+    assert np.array_equal(same, orc.forward_mt(a, q, tw, pre, n, 8))
+    two = agx.Plan(n, agx.find_primes(60, n, 2))
+    with pytest.raises(agx.AgxError) as ei:
+        two.forward_host_stream(a, a, 1)
+    assert ei.value.status == 5
+    plan.close()
+    two.close()
+
+
 def test_reference_smoke_inputs_are_reproduced(agx, orc):
     """main.cpp:49-55 feeds placeholder tables that break the precon contract; the reference
     then computes 64-bit wrap-around garbage.  Same operation sequence here, so the
@@ -232,6 +256,29 @@ def test_pointwise_and_polymul(agx, orc, dev, n, bits):
     # c aliasing a
     plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_a.data_ptr(), d_s.data_ptr(), batch, dev.stream)
     assert np.array_equal(dev.to_host(d_a), c)
+    plan.close()
+
+
+@pytest.mark.parametrize("n,bits", [(256, 60), (1024, 30), (4096, 60), (4096, 61), (4096, 62), (16384, 60)])
+def test_lazy_outputs(agx, orc, dev, n, bits):
+    """agx_ntt_forward_lazy: values in [0,4q) congruent to the transform; the inverse and the
+    pointwise product take them as they are"""
+    batch = 3
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, 1)
+    q = tabs[0][0]
+    rng = np.random.default_rng(n + bits)
+    x = rand_coeffs(rng, batch * n, q)
+    d_x, d_y = dev.to_device(x), dev.empty(x.size)
+    plan.forward_lazy(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+    y = dev.to_host(d_y)
+    want = orc.forward(x, q, tabs[0][2], tabs[0][3], n)
+    assert (y.astype(object) < 4 * q).all()
+    assert np.array_equal(y % np.uint64(q), want)
+    d_z = dev.empty(x.size)
+    plan.inverse(d_y.data_ptr(), d_z.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_z), x)
+    plan.pointwise(d_y.data_ptr(), d_y.data_ptr(), d_z.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_z), orc.pointwise(want, want, q))
     plan.close()
 
 
