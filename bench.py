@@ -60,7 +60,7 @@ def cpu_baseline(target_seconds=12.0):
     t0 = time.perf_counter()
     oracle.forward_mt(x, q, tw, pre, N_COEFF, cores)      # also the warm-up pass
     first = time.perf_counter() - t0
-    passes = max(1, min(64, int(target_seconds / max(first, 1e-3))))
+    passes = max(1, min(512, int(target_seconds / max(first, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(passes):
         oracle.forward_mt(x, q, tw, pre, N_COEFF, cores)

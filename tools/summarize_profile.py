@@ -16,7 +16,8 @@ import sys
 tag = sys.argv[1]
 want = sys.argv[2] if len(sys.argv) > 2 else "fwd_r"
 root = os.path.join("gpurun_out", f"prof_{tag}")
-lines = [f"# rocprofv3 summary `{tag}` -- `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline` on one MI355X", ""]
+lines = [f"# rocprofv3 summary `{tag}` on one MI355X -- stats pass: `python3 bench.py --no-cpu-baseline` (default 100 steps + 10 warm-up);",
+         "# PMC passes: `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline`, one counter group per run", ""]
 
 stats = glob.glob(os.path.join(root, "trace", "*", "*kernel_stats.csv"))
 avg_ns = None
