@@ -193,9 +193,17 @@ struct final_consts {   // fast forms only
     uint64_t q8, nq8;   // 8q and its negation: the conditional-subtract step of the 16q-lazy form
 };
 
-template <bool FAST>
+template <bool FAST, bool SEL = false>
 __device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k, const final_consts& f, bool lazy_out = false) {
-    if constexpr (FAST) {
+    if constexpr (FAST && SEL) {
+        const uint64_t d4 = v + k.nm;            // [0,8q) -> [0,4q)
+        v = (int64_t)d4 < 0 ? v : d4;
+        if (lazy_out) return v;
+        const uint64_t d2 = v + f.nq2;
+        v = (int64_t)d2 < 0 ? v : d2;
+        const uint64_t d1 = v + f.nq1;
+        return (int64_t)d1 < 0 ? v : d1;
+    } else if constexpr (FAST) {
         v = csub_sign(v, k);                 // [0,8q) -> [0,4q)
         if (lazy_out) return v;
         v = csub_sign_c(v, f.q2, f.nq2);     // -> [0,2q)
@@ -206,7 +214,6 @@ __device__ __forceinline__ uint64_t reduce_final(uint64_t v, const bf_consts& k,
         return csub(v, k.q);
     }
 }
-
 
 // 16q-LAZY arithmetic for q <= 2^60 (16q <= 2^64): with twice the headroom of the fast form the
 // conditional subtract is only needed when the running bound would pass 16q, which is on 5 of 12
@@ -225,15 +232,26 @@ struct lazy16_schedule {
     static constexpr int next(int b) { return (b + 4 > 16 ? (b - 8 > 8 ? b - 8 : 8) : b) + 4; }
 };
 
-template <bool SEL, bool DO_CSUB>
+// select-based conditional subtract with explicit constants
+__device__ __forceinline__ uint64_t csub_select_c(uint64_t x, uint64_t nm) {
+    const uint64_t d = x + nm;
+    return (int64_t)d < 0 ? x : d;
+}
+
+// LAST: the transform's final stage.  There tx is brought below 4q (one more subtract), so the
+// outputs are < 8q and the final reduction needs three steps per coefficient instead of four.
+template <bool SEL, bool DO_CSUB, bool LAST = false>
 __device__ __forceinline__ void ct_butterfly_lazy16(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k,
                                                     const final_consts& f) {
     const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
     uint64_t tx = x;
-    if constexpr (DO_CSUB) {
-        const uint64_t d = x + f.nq8;
-        if constexpr (SEL) tx = (int64_t)d < 0 ? x : d;
-        else tx = csub_sign_c(x, f.q8, f.nq8);
+    if constexpr (DO_CSUB || LAST) {
+        if constexpr (SEL) tx = csub_select_c(tx, f.nq8);
+        else tx = csub_sign_c(tx, f.q8, f.nq8);
+    }
+    if constexpr (LAST) {
+        if constexpr (SEL) tx = csub_select_c(tx, k.nm);
+        else tx = csub_sign(tx, k);
     }
     uint64_t c = mad64(p1, y1, (uint64_t)__umulhi(y0, p1));                  // one v_mov builds the {h,0} pair
     c = add64_32(c, __umulhi(y1, p0), k.one_b);
@@ -242,13 +260,20 @@ __device__ __forceinline__ void ct_butterfly_lazy16(uint64_t& x, uint64_t& y, ui
     x = xn;
 }
 
-// [0,16q) -> [0,q), or only to [0,4q) when the caller asked for lazy outputs
+// after a LAST butterfly: [0,8q) -> [0,q), or only to [0,4q) when the caller asked for lazy outputs
+template <bool SEL>
 __device__ __forceinline__ uint64_t reduce_final_lazy16(uint64_t v, const bf_consts& k, const final_consts& f, bool lazy_out) {
-    v = csub_sign_c(v, f.q8, f.nq8);
-    v = csub_sign(v, k);                 // 4q
-    if (lazy_out) return v;
-    v = csub_sign_c(v, f.q2, f.nq2);
-    return csub_sign_c(v, f.q1, f.nq1);
+    if constexpr (SEL) {
+        v = csub_select_c(v, k.nm);          // 4q
+        if (lazy_out) return v;
+        v = csub_select_c(v, f.nq2);
+        return csub_select_c(v, f.nq1);
+    } else {
+        v = csub_sign(v, k);
+        if (lazy_out) return v;
+        v = csub_sign_c(v, f.q2, f.nq2);
+        return csub_sign_c(v, f.q1, f.nq1);
+    }
 }
 
 // w*d - c*q (mod 2^64) with the quotient estimate of the chosen arithmetic:

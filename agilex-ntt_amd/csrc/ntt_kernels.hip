@@ -393,7 +393,7 @@ struct rb2_frame {
     // forward butterfly number `stage` of the whole transform in this frame's arithmetic
     template <int stage>
     __device__ __forceinline__ void butterfly(uint64_t& a, uint64_t& b, const twpair& w) const {
-        if constexpr (LAZY16) ct_butterfly_lazy16<SEL, lazy16_schedule::subtracts(stage)>(a, b, w.x, w.y, k, fc);
+        if constexpr (LAZY16) ct_butterfly_lazy16<SEL, lazy16_schedule::subtracts(stage), stage == S0 + L - 1>(a, b, w.x, w.y, k, fc);
         else if constexpr (FAST) ct_butterfly_fast<SEL>(a, b, w.x, w.y, k);
         else ct_butterfly_exact(a, b, w.x, w.y, k);
     }
@@ -481,11 +481,11 @@ struct rb2_frame {
                     butterfly<stage>(x[r0], x[r1], w);
                     if constexpr (last_stage) {
                         if constexpr (LAZY16) {
-                            x[r0] = reduce_final_lazy16(x[r0], k, fc, lazy_out);
-                            x[r1] = reduce_final_lazy16(x[r1], k, fc, lazy_out);
+                            x[r0] = reduce_final_lazy16<SEL>(x[r0], k, fc, lazy_out);
+                            x[r1] = reduce_final_lazy16<SEL>(x[r1], k, fc, lazy_out);
                         } else {
-                            x[r0] = reduce_final<FAST>(x[r0], k, fc, lazy_out);
-                            x[r1] = reduce_final<FAST>(x[r1], k, fc, lazy_out);
+                            x[r0] = reduce_final<FAST, SEL>(x[r0], k, fc, lazy_out);
+                            x[r1] = reduce_final<FAST, SEL>(x[r1], k, fc, lazy_out);
                         }
                     }
                 });
