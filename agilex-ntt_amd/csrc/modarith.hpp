@@ -317,9 +317,12 @@ __device__ __forceinline__ void gs_last_form(uint64_t& x, uint64_t& y, uint64_t 
 }
 
 // [0,m) -> [0,q) after the inverse transform
-template <bool FAST>
+template <bool FAST, bool SEL = false>
 __device__ __forceinline__ uint64_t reduce_final_inv(uint64_t v, const bf_consts& k, const final_consts& f) {
-    if constexpr (FAST) {
+    if constexpr (FAST && SEL) {
+        v = csub_select_c(v, f.nq2);
+        return csub_select_c(v, f.nq1);
+    } else if constexpr (FAST) {
         v = csub_sign_c(v, f.q2, f.nq2);
         return csub_sign_c(v, f.q1, f.nq1);
     } else {

@@ -529,8 +529,8 @@ struct rb2_frame {
                         gs_butterfly_form<FAST, SEL>(x[r0], x[r1], w.x, w.y, k);
                     }
                     if constexpr (top_stage) {
-                        x[r0] = reduce_final_inv<FAST>(x[r0], k, fc);
-                        x[r1] = reduce_final_inv<FAST>(x[r1], k, fc);
+                        x[r0] = reduce_final_inv<FAST, SEL>(x[r0], k, fc);
+                        x[r1] = reduce_final_inv<FAST, SEL>(x[r1], k, fc);
                     }
                 }
             });

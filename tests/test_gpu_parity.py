@@ -439,3 +439,38 @@ def test_config5_polymul_32768(agx, orc, dev):
     want = orc.inverse(orc.pointwise(orc.forward(a2, q, tw, pre, n), orc.forward(b[:n], q, tw, pre, n), q), q, itw, n)
     assert np.array_equal(dev.to_host(d_c)[:n], want)
     plan.close()
+
+
+def test_randomised_shapes_against_oracle(agx, orc, dev):
+    """40 random (n, modulus size, primes, batch, in/out of place, lazy) forward + inverse cases:
+    every size class, every arithmetic form, ragged batches"""
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        n = 1 << int(rng.integers(1, 16))
+        bits = int(rng.choice([max(20, n.bit_length() + 2), 30, 45, 59, 60, 61, 62]))
+        if bits <= n.bit_length() + 1:
+            bits = n.bit_length() + 4
+        primes = int(rng.integers(1, 4)) if n <= 8192 else 1
+        batch = int(rng.integers(1, 8)) if n <= 8192 else int(rng.integers(1, 3))
+        plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
+        x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=int(rng.integers(1, 5))) for t in tabs])
+        d_x = dev.to_device(x)
+        in_place = bool(rng.integers(0, 2))
+        d_y = d_x if in_place else dev.empty(x.size)
+        lazy = bool(rng.integers(0, 2))
+        (plan.forward_lazy if lazy else plan.forward)(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+        y = dev.to_host(d_y)
+        want = _oracle_forward_rns(orc, x, tabs, n, batch)
+        for p, t in enumerate(tabs):
+            sl = slice(p * batch * n, (p + 1) * batch * n)
+            if lazy:
+                assert (y[sl].astype(object) < 4 * t[0]).all(), (case, n, bits)
+                assert np.array_equal(y[sl] % np.uint64(t[0]), want[sl]), (case, n, bits, primes, batch)
+            else:
+                assert np.array_equal(y[sl], want[sl]), (case, n, bits, primes, batch, in_place)
+        plan.inverse(d_y.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+        back = dev.to_host(d_y)
+        for p, t in enumerate(tabs):
+            sl = slice(p * batch * n, (p + 1) * batch * n)
+            assert np.array_equal(back[sl], x[sl] % np.uint64(t[0])), (case, n, bits, "inverse")
+        plan.close()
