@@ -351,7 +351,7 @@ int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint
     const plan_view pv = view_of(plan);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool fast_path = use_regblock(plan) && regblock_has_inverse(plan->rb) && plan->d_itw_rb;
-    AGX_HIP(fast_path ? launch_inverse_regblock(pv, d_in, d_out, fl, s) : launch_inverse_radix2(pv, d_in, d_out, fl, s));
+    AGX_HIP(fast_path ? launch_inverse_regblock(pv, d_in, nullptr, d_out, fl, s) : launch_inverse_radix2(pv, d_in, d_out, fl, s));
     return AGX_OK;
 }
 
@@ -387,7 +387,17 @@ int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_
     if (!d_scratch) return AGX_ERR_NULL_POINTER;
     if (d_scratch == d_a || d_scratch == d_b || d_scratch == d_c) return AGX_ERR_BAD_ARGUMENT;
     int rc;
-    // scratch <- NTT(a); c <- NTT(b) (a is dead by now, so c may alias it); c <- c o scratch; c <- INTT(c)
+    // scratch <- NTT(a); c <- NTT(b) (a is dead by now, so c may alias it); c <- INTT(c o scratch).
+    // With the register-blocked inverse the product is taken while it loads (no pointwise pass) and
+    // the forward results may stay lazily reduced.
+    const bool fused_tail = use_regblock(plan) && regblock_has_inverse(plan->rb) && plan->d_itw_rb;
+    if (fused_tail) {
+        if ((rc = agx_ntt_forward_lazy(plan, d_a, d_scratch, batch, stream))) return rc;
+        if ((rc = agx_ntt_forward_lazy(plan, d_b, d_c, batch, stream))) return rc;
+        const frame_layout fl{batch, (int64_t)(batch * plan->n), (int64_t)plan->n};
+        AGX_HIP(launch_inverse_regblock(view_of(plan), d_c, d_scratch, d_c, fl, static_cast<hipStream_t>(stream)));
+        return AGX_OK;
+    }
     if ((rc = agx_ntt_forward(plan, d_a, d_scratch, batch, stream))) return rc;
     if ((rc = agx_ntt_forward(plan, d_b, d_c, batch, stream))) return rc;
     if ((rc = agx_ntt_pointwise(plan, d_c, d_scratch, d_c, batch, stream))) return rc;

@@ -553,11 +553,18 @@ struct rb2_frame {
             static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[base + e0 + 64u * (uint32_t)r] = slab[join(s0, img(64u * (uint32_t)r))]; });
         }
     }
-    __device__ __forceinline__ void load_last_layout(uint64_t (&x)[C], const uint64_t* __restrict__ in, int64_t base) const {
+    // `in2` (may be null): the coefficient-wise product in * in2 mod q is taken while loading, so a
+    // polynomial product needs no separate pointwise pass before its inverse transform
+    __device__ __forceinline__ void load_last_layout(uint64_t (&x)[C], const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2,
+                                                     const barrett128& bk, int64_t base) const {
         const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
 #pragma unroll
         for (int r = 0; r < C; ++r) {
             uint64_t v = in[base + e0 + 64u * (uint32_t)r];
+            if (in2) {   // wave-uniform
+                const uint64_t u = in2[base + e0 + 64u * (uint32_t)r];
+                v = mul_mod_barrett(reduce_4q(v, k.q, k.q << 1), reduce_4q(u, k.q, k.q << 1), bk);
+            }
             if constexpr (!FAST) v = csub(v, k.m);    // exact form wants [0,2q); inputs may be < 4q
             slab[join(s0, img(64u * (uint32_t)r))] = v;
         }
@@ -665,14 +672,16 @@ fwd_rb2_split(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
 
 template <int L, int R, int PPB, int ARITH, int MINW>
 __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
-inv_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+inv_rb2(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint64_t* __restrict__ out,
         const prime_consts* __restrict__ consts, const twpair* __restrict__ itw_rb,
         uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
         int64_t prime_stride, int64_t poly_stride) {
     AGX_RB2_PROLOGUE;
+    const prime_consts pc = consts[prime];
+    const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
     uint64_t x[C];
-    f.load_last_layout(x, in, base);
-    f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, consts[prime]);
+    f.load_last_layout(x, in, in2, bk, base);
+    f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);
     if (live) {
 #pragma unroll
         for (int r = 0; r < C; ++r) out[base + f.tid + (uint32_t)r * T] = x[r];
@@ -764,7 +773,7 @@ struct rb_entry {
     hipError_t (*launch)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     hipError_t (*init)();
     int arith;   // 0: exact (reference op sequence, q < 2^62); 1: fast (q <= 2^61); 2: 16q-lazy (q <= 2^60)
-    hipError_t (*launch_inv)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    hipError_t (*launch_inv)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     hipError_t (*launch_mul)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     int fused_split;   // S > 0: `launch` is only for out != in and computes the S leading stages itself (n = 2^(log_local+S))
     hipError_t (*launch_fused)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
@@ -834,12 +843,12 @@ hipError_t launch_rb2_t(const plan_view& pv, const uint64_t* in, uint64_t* out, 
 
 
 template <int L, int R, int PPB, int ARITH, int MINW>
-hipError_t launch_inv_rb2_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+hipError_t launch_inv_rb2_t(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     const uint64_t frames_x = fl.batch << pv.rb.log_split;
     dim3 grid((unsigned)((frames_x + PPB - 1) / PPB), pv.num_primes);
     const size_t lds = rb2_lds_bytes<L, R, PPB, ARITH>();
-    hipLaunchKernelGGL((inv_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), lds, s, in, out, pv.consts,
+    hipLaunchKernelGGL((inv_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), lds, s, in, in2, out, pv.consts,
                        pv.itw_rb, pv.rb.pairs_per_prime, (uint32_t)pv.rb.log_split, frames_x, fl.prime_stride, fl.poly_stride);
     return hipGetLastError();
 }
@@ -1085,10 +1094,10 @@ bool regblock_has_polymul(const regblock_layout& rb) {
     return e && e->launch_mul && rb.log_split == 0 && rb.log_local <= 13;   // 2^14: 1024 threads x 128 VGPRs cannot hold two frames
 }
 
-hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     const rb_entry* e = rb_lookup(pv.rb.config_id);
     if (!e || !e->launch_inv || !pv.itw_rb) return hipErrorInvalidValue;
-    hipError_t err = e->launch_inv(pv, in, out, fl, s);
+    hipError_t err = e->launch_inv(pv, in, in2, out, fl, s);
     if (err != hipSuccess) return err;
     for (int st = pv.rb.log_split - 1; st >= 0; --st) {   // stages with a gap wider than the resident block
         dim3 g2(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);

@@ -58,7 +58,8 @@ hipError_t launch_inverse_radix2(const plan_view& pv, const uint64_t* in, uint64
 hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
 bool regblock_has_inverse(const regblock_layout& rb);
 bool regblock_has_polymul(const regblock_layout& rb);   // fused NTT -> pointwise -> INTT in one kernel
-hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
+// in2 != null: transforms the coefficient-wise product in * in2 (the pointwise step fused into the load)
+hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s);
 hipError_t launch_polymul_regblock(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, const frame_layout& fl, hipStream_t s);
 hipError_t launch_pointwise(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, uint64_t batch, hipStream_t s);
 hipError_t launch_fill(const plan_view& pv, uint64_t* out, uint64_t batch, uint64_t first_poly, uint64_t seed, hipStream_t s);
