@@ -422,6 +422,21 @@ int agx_ntt_forward_host_stream(const agx_ntt_plan* plan, const uint64_t* in, co
     if (plan->num_primes != 1) return AGX_ERR_BAD_ARGUMENT;   // one modulus per stream, as the reference (ntt.cpp:143-144)
     if (num_frames == 0) return AGX_OK;
     const size_t n = plan->n, row = n * sizeof(uint64_t), half = row / 2;
+    if (num_frames * row <= ((size_t)4 << 20)) {
+        // small inputs: staging buffers and streams would cost more than they hide
+        uint64_t* d = nullptr;
+        hipError_t se = hipMalloc(reinterpret_cast<void**>(&d), row * num_frames);
+        int src = AGX_OK;
+        if (se == hipSuccess) se = hipMemcpy2D(d, row, in, row, half, num_frames, hipMemcpyHostToDevice);
+        if (se == hipSuccess) se = hipMemcpy2D(reinterpret_cast<char*>(d) + half, row, reinterpret_cast<const char*>(in2) + half, row, half, num_frames, hipMemcpyHostToDevice);
+        if (se == hipSuccess) {
+            src = agx_ntt_forward(plan, d, d, num_frames, nullptr);
+            if (src == AGX_OK) se = hipMemcpy(out, d, row * num_frames, hipMemcpyDeviceToHost);
+        }
+        if (d) (void)hipFree(d);
+        if (src != AGX_OK) return src;
+        return se == hipSuccess ? AGX_OK : hip_fail(se);
+    }
     constexpr int kSlots = 3;
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(num_frames, ((size_t)32 << 20) / row));
     const uint64_t nchunks = (num_frames + chunk - 1) / chunk;
