@@ -299,21 +299,22 @@ fwd_regblock(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
 }
 
 // ---------------------------------------------------------------------------------------
-// register-blocked forward kernel, second generation (the throughput path).
+// second-generation register-blocked kernels (the throughput path): forward, inverse and fused
+// polynomial product share rb2_frame below.
 //
-// Same pass structure as fwd_regblock; what changed, each item from a measurement:
-//  * hand-selected butterfly forms (modarith.hpp): 20 VALU (fast, q <= 2^61) / 27 (exact)
-//    instead of ~32, because VOP3 integer ops all issue at half rate on gfx950;
+// Same pass structure as fwd_regblock; what changed, each item from a measurement (DESIGN.md 3):
+//  * hand-selected butterfly forms (modarith.hpp): 15-19 VALU instead of ~32, because every VOP3
+//    integer op issues at quarter/half rate on gfx950 and the kernel is VALU bound;
+//  * R = 3 (8 coefficients per thread, <= 64 VGPRs): 8 waves/SIMD issue multiplies 34 % faster than 4;
 //  * passes whose twiddle column depends only on the wave index (rlo >= 6) read their twiddles
-//    with scalar loads into SGPRs: no VGPRs, no VALU, no vector-memory traffic for them;
+//    with wide scalar loads into SGPRs: no VGPRs, no VALU, no vector-memory traffic for them;
 //  * an exchange that only moves coefficients between lanes of the same wave needs no
 //    workgroup barrier (one wave's LDS operations execute in program order); which exchanges
-//    those are is decided at compile time by exchange_is_wave_local();
-//  * XOR-swizzled LDS image instead of padding: conflict-free for the contiguous, the
-//    stride-8 and the mixed (low 3 bits + bits 6..8) lane patterns the R = 3 passes produce,
-//    and exactly n*8 bytes per frame;
+//    those are is decided at compile time by exchange_is_wave_local(): one s_barrier per frame;
+//  * LDS image padded by one word per 16 (default) so every exchange access is thread base +
+//    immediate offset; the XOR-swizzled image (conflict-free, exactly 8n bytes) is kept as an option;
 //  * results leave through the LDS image as coalesced stores (each wave owns a contiguous
-//    chunk of the frame after the first exchange).
+//    chunk of the frame after the first exchange); direct 16-byte strided stores measured 5 % slower.
 // ---------------------------------------------------------------------------------------
 template <int L, int R>
 struct rb2_geom : rb_geom<L, R> {
