@@ -30,6 +30,8 @@ struct agx_ntt_plan {
     regblock_layout rb;
     regblock_layout rb_oop;            // forward layout used when out != in (fused-split kernels), or invalid
     ulonglong2* d_tw_rb_oop = nullptr;
+    regblock_layout rb_fip;            // forward layout used when out == in (pair kernels), or invalid
+    ulonglong2* d_tw_rb_fip = nullptr;
 };
 
 namespace {
@@ -80,6 +82,7 @@ void free_plan(agx_ntt_plan* p) {
     if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
     if (p->d_itw_rb) (void)hipFree(p->d_itw_rb);
     if (p->d_tw_rb_oop) (void)hipFree(p->d_tw_rb_oop);
+    if (p->d_tw_rb_fip) (void)hipFree(p->d_tw_rb_fip);
     delete p;
 }
 
@@ -134,8 +137,9 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         }
     }
     p->rb = regblock_choose(n, -1, p->arith_level);
-    p->rb_oop = regblock_choose_out_of_place(n, p->arith_level);
-    std::vector<ulonglong2> rb_pairs, irb_pairs, oop_pairs;
+    p->rb_oop = regblock_choose_forward_only(n, p->arith_level, false);
+    p->rb_fip = regblock_choose_forward_only(n, p->arith_level, true);
+    std::vector<ulonglong2> rb_pairs, irb_pairs, oop_pairs, fip_pairs;
     for (uint32_t k = 0; k < num_primes; ++k) {
         const uint64_t q = moduli[k];
         prime_consts& c = consts[k];
@@ -159,6 +163,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         }
         if (p->rb.valid()) regblock_build_table(p->rb, twk, prek, rb_pairs);
         if (p->rb_oop.valid()) regblock_build_table(p->rb_oop, twk, prek, oop_pairs);
+        if (p->rb_fip.valid()) regblock_build_table(p->rb_fip, twk, prek, fip_pairs);
     }
     if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
     if ((rc = upload(&p->d_tw, tw_pairs)) != AGX_OK) { free_plan(p); return rc; }
@@ -166,6 +171,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     if (p->rb.valid() && (rc = upload(&p->d_tw_rb, rb_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && itw && (rc = upload(&p->d_itw_rb, irb_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb_oop.valid() && (rc = upload(&p->d_tw_rb_oop, oop_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (p->rb_fip.valid() && (rc = upload(&p->d_tw_rb_fip, fip_pairs)) != AGX_OK) { free_plan(p); return rc; }
     *out = p;
     return AGX_OK;
 }
@@ -289,9 +295,12 @@ int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant) {
     }
     if (config_id >= 0) {
         plan->rb_oop = regblock_layout{};            // an explicit kernel choice applies to every call
-    } else if (!plan->rb_oop.valid() && variant != AGX_VARIANT_LDS_RADIX2) {
-        const regblock_layout oop = regblock_choose_out_of_place(plan->n, plan->arith_level);
-        if (oop.valid() && plan->d_tw_rb_oop) plan->rb_oop = oop;   // tables were built at creation
+        plan->rb_fip = regblock_layout{};
+    } else if (variant != AGX_VARIANT_LDS_RADIX2) {  // tables were built at creation
+        const regblock_layout oop = regblock_choose_forward_only(plan->n, plan->arith_level, false);
+        const regblock_layout fip = regblock_choose_forward_only(plan->n, plan->arith_level, true);
+        if (oop.valid() && plan->d_tw_rb_oop) plan->rb_oop = oop;
+        if (fip.valid() && plan->d_tw_rb_fip) plan->rb_fip = fip;
     }
     plan->variant = variant;
     return AGX_OK;
@@ -323,9 +332,14 @@ static int forward_common(const agx_ntt_plan* plan, const uint64_t* d_in, uint64
     fl.lazy_out = lazy_out;
     plan_view pv = view_of(plan);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (d_in != d_out && plan->rb_oop.valid() && plan->variant != AGX_VARIANT_LDS_RADIX2) {
-        pv.rb = plan->rb_oop;
-        pv.tw_rb = plan->d_tw_rb_oop;
+    if (plan->variant != AGX_VARIANT_LDS_RADIX2) {   // forward-only layouts, where n has them
+        if (d_in != d_out && plan->rb_oop.valid()) {
+            pv.rb = plan->rb_oop;
+            pv.tw_rb = plan->d_tw_rb_oop;
+        } else if (d_in == d_out && plan->rb_fip.valid()) {
+            pv.rb = plan->rb_fip;
+            pv.tw_rb = plan->d_tw_rb_fip;
+        }
     }
     AGX_HIP(use_regblock(plan) ? launch_forward_regblock(pv, d_in, d_out, fl, s) : launch_forward_radix2(pv, d_in, d_out, fl, s));
     return AGX_OK;

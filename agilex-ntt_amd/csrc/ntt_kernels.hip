@@ -671,6 +671,41 @@ fwd_rb2_split(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     f.store_last_layout(x, out, base, live);
 }
 
+// Frames of 2^(L+1) coefficients, in-place safe, 16n bytes of traffic: one workgroup loads the whole
+// frame (each thread its 2^R butterfly pairs of the leading stage), runs that stage once, then
+// transforms the two resident halves one after the other through the same LDS image while the
+// second half waits in registers.  Nothing is stored before everything has been loaded.
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+fwd_rb2_pair(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+             const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_nat, const twpair* __restrict__ tw_rb,
+             uint32_t pairs_per_prime, int64_t prime_stride, int64_t poly_stride, uint32_t lazy_out) {
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1), 1>;
+    constexpr int C = F::C, T = F::T;
+    F f;
+    f.tid = threadIdx.x;
+    const uint32_t prime = blockIdx.y;
+    f.split_log = 1;
+    f.lazy_out = lazy_out != 0;
+    f.init_consts(consts[prime].q);
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    const int64_t frame = (int64_t)prime * prime_stride + (int64_t)blockIdx.x * poly_stride;
+    const twpair* tbl = tw_rb + (size_t)prime * pairs_per_prime;
+    const twpair w1 = load_uniform(tw_nat + ((size_t)prime << (L + 1)) + 1);
+
+    uint64_t lo[C], hi[C];
+    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; lo[r] = in[frame + f.tid + (uint32_t)r * T]; });
+    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; hi[r] = in[frame + (1 << L) + f.tid + (uint32_t)r * T]; });
+    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; f.template butterfly<0>(lo[r], hi[r], w1); });
+    f.blk = 0;
+    f.forward(lo, tbl);
+    f.store_last_layout(lo, out, frame, true);
+    __syncthreads();   // the second half's first exchange scatters over the whole image
+    f.blk = 1;
+    f.forward(hi, tbl);
+    f.store_last_layout(hi, out, frame + (1 << L), true);
+}
+
 template <int L, int R, int PPB, int ARITH, int MINW>
 __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 inv_rb2(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint64_t* __restrict__ out,
@@ -778,6 +813,7 @@ struct rb_entry {
     hipError_t (*launch_mul)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     int fused_split;   // S > 0: `launch` is only for out != in and computes the S leading stages itself (n = 2^(log_local+S))
     hipError_t (*launch_fused)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    bool fused_in_place_ok;   // launch_fused loads a whole frame before it stores any of it
 };
 
 template <int L, int R, bool col_major = false>
@@ -878,7 +914,7 @@ constexpr rb_entry make_entry2(int id) {
     return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, rb2_lds_bytes<L, R, PPB, ARITH>(),
                     &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>,
                     (ARITH & 1) ? ((((ARITH >> 1) & kOptLazy16) != 0) ? 2 : 1) : 0,
-                    &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>, 0, nullptr};
+                    &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>, 0, nullptr, false};
 }
 
 template <int L, int R, int PPB, int ARITH, int MINW, int S>
@@ -901,6 +937,37 @@ hipError_t init_rb2_split_t() {
     return e;
 }
 
+template <int L, int R, int ARITH, int MINW>
+hipError_t launch_rb2_pair_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>();
+    dim3 grid((unsigned)fl.batch, pv.num_primes);
+    hipLaunchKernelGGL((fwd_rb2_pair<L, R, ARITH, MINW>), grid, dim3(G::T), lds, s, in, out, pv.consts, pv.tw, pv.tw_rb,
+                       pv.rb.pairs_per_prime, fl.prime_stride, fl.poly_stride, (uint32_t)(fl.lazy_out ? 1 : 0));
+    return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t init_rb2_pair_t() {
+    hipError_t e = init_rb2_t<L, R, 1, ARITH, MINW>();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_pair<L, R, ARITH, MINW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb2_lds_bytes<L, R, 1, ARITH>());
+    return e;
+}
+
+// n = 2^(L+1) with one workgroup per frame transforming its two halves in turn (in-place safe);
+// the inverse of such a plan runs on the 2^L blocks + inv_global_stage
+template <int L, int R, int ARITH, int MINW>
+constexpr rb_entry make_entry_pair(int id) {
+    rb_entry e = make_entry2<L, R, 1, ARITH, MINW>(id);
+    e.init = &init_rb2_pair_t<L, R, ARITH, MINW>;
+    e.fused_split = 1;
+    e.launch_fused = &launch_rb2_pair_t<L, R, ARITH, MINW>;
+    e.fused_in_place_ok = true;
+    return e;
+}
+
 // a second-generation entry for n = 2^(L+S): resident blocks of 2^L, leading S stages fused into the
 // forward kernel when out != in (in place they run as separate fwd_global_stage passes)
 template <int L, int R, int PPB, int ARITH, int MINW, int S>
@@ -915,7 +982,7 @@ constexpr rb_entry make_entry_split(int id) {
 template <int L, int R, int PPB, bool STAGE_OUT, int MINW>
 constexpr rb_entry make_entry(int id) {
     return rb_entry{id, L, R, PPB, STAGE_OUT, MINW, (uint32_t)rb_geom<L, R>::table_pairs, (size_t)rb_geom<L, R>::lds_elems * 8 * PPB,
-                    &build_table_t<L, R>, &launch_rb_t<L, R, PPB, STAGE_OUT, MINW>, &init_rb_t<L, R, PPB, STAGE_OUT, MINW>, 0, nullptr, nullptr, 0, nullptr};
+                    &build_table_t<L, R>, &launch_rb_t<L, R, PPB, STAGE_OUT, MINW>, &init_rb_t<L, R, PPB, STAGE_OUT, MINW>, 0, nullptr, nullptr, 0, nullptr, false};
 }
 
 // ids are stable handles for tests and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices
@@ -952,6 +1019,10 @@ const rb_entry kRbEntries[] = {
     make_entry_split<13, 3, 1, 0 | (kOptPad << 1), 8, 2>(47),
     make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8, 2>(48),
     make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8, 2>(49),
+    // n = 16384: one workgroup per frame, its two 8192-halves in turn (in-place safe, no redundant work)
+    make_entry_pair<13, 3, 0 | (kOptPad << 1), 8>(51),
+    make_entry_pair<13, 3, 1 | ((kOptPad | kOptSelect) << 1), 8>(52),
+    make_entry_pair<13, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(53),
 };
 
 const rb_entry* rb_lookup(int id) {
@@ -1007,10 +1078,18 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
     return rb;
 }
 
-// tuned configuration for out-of-place forward calls, where a fused-split kernel may read the whole
-// frame from every block; invalid layout when n has none
-regblock_layout regblock_choose_out_of_place(uint32_t n, int arith_level) {
-    static const int kOop[] = {46, 45, 44, 49, 48, 47};
+// tuned forward-only configurations for the sizes whose frames exceed one 8-waves/SIMD workgroup:
+// out of place a fused-split kernel (every block may read the whole frame), in place a pair kernel;
+// invalid layout when n has none (the plan's main layout then serves forward calls too)
+regblock_layout regblock_choose_forward_only(uint32_t n, int arith_level, bool in_place) {
+    static const int kOop[] = {46, 45, 44, 49, 48, 47};   // fused-split kernels: every block reads the whole frame
+    static const int kInPlace[] = {53, 52, 51};           // pair kernels: a workgroup owns the whole frame
+    for (int id : kInPlace) {
+        if (!in_place) break;
+        regblock_layout rb = regblock_choose(n, id, arith_level);
+        if (rb.valid()) return rb;
+    }
+    if (in_place) return regblock_layout{};
     for (int id : kOop) {
         regblock_layout rb = regblock_choose(n, id, arith_level);
         if (rb.valid()) return rb;
@@ -1074,7 +1153,7 @@ hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint
     if (!pv.rb.valid()) return hipErrorInvalidValue;
     const rb_entry* e = rb_lookup(pv.rb.config_id);
     if (!e) return hipErrorInvalidValue;
-    if (e->fused_split > 0 && in != out) return e->launch_fused(pv, in, out, fl, s);   // every block reads the whole frame
+    if (e->fused_split > 0 && (in != out || e->fused_in_place_ok)) return e->launch_fused(pv, in, out, fl, s);
     const uint64_t* src = in;
     for (int st = 0; st < pv.rb.log_split; ++st) {
         dim3 grid(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);

@@ -48,7 +48,7 @@ struct frame_layout {
 // config_id -1: tuned default for n; arith_level: 0 exact only, 1 every modulus <= 2^61 (fast form legal),
 // 2 every modulus <= 2^60 (16q-lazy form legal)
 regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level);
-regblock_layout regblock_choose_out_of_place(uint32_t n, int arith_level);   // fused-split forward (out != in) or invalid
+regblock_layout regblock_choose_forward_only(uint32_t n, int arith_level, bool in_place);   // forward-only layouts or invalid
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out);
 
 hipError_t kernels_init();  // one-time function attributes (large dynamic LDS)
