@@ -21,6 +21,12 @@
  *                 from the reference's own butterfly code (tests/golden/
  *                 survey_anchors.json) and (ii) an independent O(n^2) evaluation
  *                 of the closed-form contract (oracle_naive_forward below).
+ *                 Honest size of pin (i): the reference prime / root for six sizes and
+ *                 five explicit output words (n=1024: out[0..3]; n=4096: out[0]); the
+ *                 FNV checksums SURVEY lists could not be reproduced from its
+ *                 description of the hash and are not asserted.  Beyond those words the
+ *                 forward path is pinned by mathematics only -- treat it as PARTIALLY
+ *                 pinned ("parity unpinned" for anything the five words do not cover).
  *   inverse NTT, pointwise multiply, polymul: "parity unpinned" -- the reference
  *                 has no such code; pinned by mathematics only
  *                 (round trip, naive inverse, schoolbook negacyclic product).
