@@ -300,6 +300,31 @@ def test_strided_poly_major_layout(agx, orc, dev):
     plan.close()
 
 
+@pytest.mark.parametrize("n", [16384, 32768])
+def test_large_frames_strided_in_and_out_of_place(agx, orc, dev, n):
+    """n=16384/32768 have dedicated forward kernels per call shape (pair kernel in place, fused-split
+    out of place); both must honour strides: [poly][prime][n] layout, 2 primes, ragged batch"""
+    batch, primes = 3, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
+    rng = np.random.default_rng(n + 3)
+    x = np.empty((batch, primes, n), dtype=np.uint64)
+    for p in range(primes):
+        x[:, p, :] = rand_coeffs(rng, batch * n, tabs[p][0], hi_mult=4).reshape(batch, n)
+    want = np.empty_like(x)
+    for p, (q, _, tw, pre) in enumerate(tabs):
+        want[:, p, :] = orc.forward(np.ascontiguousarray(x[:, p, :]).reshape(-1), q, tw, pre, n).reshape(batch, n)
+    d_in = dev.to_device(x.reshape(-1))
+    d_out = dev.empty(x.size)
+    plan.forward_strided(d_in.data_ptr(), d_out.data_ptr(), batch, n, primes * n, dev.stream)     # out of place
+    assert np.array_equal(dev.to_host(d_out).reshape(batch, primes, n), want)
+    assert np.array_equal(dev.to_host(d_in), x.reshape(-1))
+    plan.forward_strided(d_in.data_ptr(), d_in.data_ptr(), batch, n, primes * n, dev.stream)      # in place
+    assert np.array_equal(dev.to_host(d_in).reshape(batch, primes, n), want)
+    plan.inverse_strided(d_in.data_ptr(), d_in.data_ptr(), batch, n, primes * n, dev.stream)
+    assert np.array_equal(dev.to_host(d_in).reshape(batch, primes, n), x % np.array([t[0] for t in tabs], dtype=np.uint64)[None, :, None])
+    plan.close()
+
+
 def test_empty_batch_and_errors(agx, dev):
     q = agx.find_primes(60, 4096)[0]
     plan = agx.Plan(4096, [q])
