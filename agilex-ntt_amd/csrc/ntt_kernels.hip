@@ -357,6 +357,7 @@ __device__ __forceinline__ twpair load_uniform(const twpair* p) {
 // option bits of the second-generation kernels (A/B switches; the tuned defaults are in the registry)
 constexpr int kOptPad = 1;       // padded LDS image, exchanges addressed base + immediate offset
 constexpr int kOptSelect = 2;    // conditional subtract by compare + select instead of sign mask
+constexpr int kOptTwAhead = 32;   // per-lane passes: first three table entries fetched one pass early, the rest at pass start
 constexpr int kOptLazy16 = 16;   // q <= 2^60: 16q-lazy forward butterflies (conditional subtract on 5 of 12 stages)
 
 // per-frame state shared by the second-generation kernels
@@ -365,6 +366,9 @@ struct rb2_frame {
     using G = rb2_geom<L, R>;
     static constexpr int C = G::C, T = G::T, NP = G::NP;
     static constexpr bool PAD = (OPT & kOptPad) != 0, SEL = (OPT & kOptSelect) != 0, LAZY16 = FAST && (OPT & kOptLazy16) != 0;
+    static constexpr bool TWA = (OPT & kOptTwAhead) != 0 && R == 3;
+    // a per-lane pass with all R stages: the shape the look-ahead twiddle fetch handles
+    static constexpr bool lane_full_pass(int p) { return p >= 0 && p < NP && G::rlo(p) < 6 && G::hi(p) - G::rlo(p) + 1 == R; }
     static constexpr uint32_t slab_elems = PAD ? (1u << L) + (1u << (L - 4)) : (1u << L);
     // image word of coefficient e; both forms are additive over disjoint bit fields, which is what
     // lets an exchange address register r as (thread base) combined with a compile-time constant
@@ -452,32 +456,55 @@ struct rb2_frame {
         else __builtin_amdgcn_wave_barrier();
     }
 
-    // x in pass-0 layout (element tid + T*r, any values in [0,2m)) -> forward transform, x in the
-    // last pass's layout (elements tid*C .. tid*C+C-1), fully reduced
     // forward passes [P0, P1): pass P0 reads the image unless it is pass 0 (x already holds the
-    // pass-0 layout); every pass but the last writes the image; `sync_first` = order the exchange
-    // that precedes pass P0 (split out so a caller can put work between the write and the sync)
+    // pass-0 layout) and first orders the exchange that precedes it; every pass but the last
+    // writes the image
     template <int P0, int P1>
     __device__ __forceinline__ void forward_passes(uint64_t (&x)[C], const twpair* tbl) const {
+        // look-ahead twiddles (TWA): entries 1..3 of the next per-lane pass are requested during the
+        // last stage of the current pass, entries 4..7 at the start of their own pass, so the L2
+        // latency of the per-lane table reads overlaps butterflies instead of stalling the wave
+        twpair ahead[4];
         static_for<P0, P1>([&](auto P) {
             constexpr int p = P;
-            constexpr int rlo = G::rlo(p), hi = G::hi(p);
+            constexpr int rlo = G::rlo(p), hi = G::hi(p), ns = hi - rlo + 1;
+            constexpr bool twa_here = TWA && lane_full_pass(p);
+            constexpr bool twa_prev = TWA && p > P0 && lane_full_pass(p);   // the previous pass fetched `ahead` for us
+            constexpr bool twa_next = TWA && p + 1 < P1 && lane_full_pass(p + 1);
             tw_src<p> t;
             fetch<p>(t, tbl);
+            twpair late[4];
+            if constexpr (twa_here) {
+                if constexpr (!twa_prev) {
+                    static_for<1, 4>([&](auto J) { constexpr int j = J; ahead[j] = t.col[(size_t)j * t.hstride]; });
+                }
+                static_for<0, 4>([&](auto J) { constexpr int j = J; late[j] = t.col[(size_t)(j + 4) * t.hstride]; });
+            }
             if constexpr (p > 0) {
                 if constexpr (p == P0) exchange_sync<p - 1>();
                 image_read<p>(x);
             }
-            static_for<0, hi - rlo + 1>([&](auto S) {
+            static_for<0, ns>([&](auto S) {
                 constexpr int rb = (hi - rlo) - S;        // gap bits descend: Cooley-Tukey
                 constexpr int kk = R - 1 - rb;
                 constexpr bool last_stage = (rlo + rb) == 0;
+                if constexpr (twa_next && S == (ns > 1 ? ns - 1 : 0)) {
+                    // `ahead` is free once this pass's first two stages are done
+                    constexpr int pn = p + 1;
+                    const twpair* ncol = tbl + G::table_off(pn) * (1u << split_log) + (size_t)blk * G::H(pn) + (tid >> G::rlo(pn));
+                    const uint32_t nstride = (uint32_t)G::H(pn) << split_log;
+                    static_for<1, 4>([&](auto J) { constexpr int j = J; ahead[j] = ncol[(size_t)j * nstride]; });
+                }
                 static_for<0, C / 2>([&](auto B) {
                     // B-th butterfly of the stage: insert a 0 at register bit rb
                     constexpr int b = B;
                     constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
                     constexpr int r1 = r0 | (1 << rb);
-                    const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
+                    constexpr int j = (1 << kk) + (r0 >> (rb + 1));
+                    twpair w;
+                    if constexpr (twa_here && j < 4) w = ahead[j];
+                    else if constexpr (twa_here) w = late[j - 4];
+                    else w = twiddle<p>(t, j);
                     constexpr int stage = S0 + L - 1 - (rlo + rb);   // position in the whole transform
                     butterfly<stage>(x[r0], x[r1], w);
                     if constexpr (last_stage) {
@@ -1000,6 +1027,7 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 0 | (kOptPad << 1), 8>(28),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(27),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(39),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8>(50),
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(40),
@@ -1062,7 +1090,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
         if (e && (split_for(*e) < 0 || e->arith > arith_level)) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
-        static const int kDefaults[] = {39, 27, 28, 40, 29, 30, 41, 31, 32, 42, 33, 34, 43, 35, 36, 0, 1, 2, 3, 4};
+        static const int kDefaults[] = {50, 39, 27, 28, 40, 29, 30, 41, 31, 32, 42, 33, 34, 43, 35, 36, 0, 1, 2, 3, 4};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
             if (c && split_for(*c) >= 0 && c->arith <= arith_level) { e = c; break; }

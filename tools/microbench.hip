@@ -3,6 +3,7 @@
 // (ii) streaming copy bandwidth for the access shapes the NTT kernels use.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip
 #include <hip/hip_runtime.h>
+#include "../agilex-ntt_amd/csrc/modarith.hpp"
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -224,10 +225,80 @@ static void time_bw(const char* name, size_t bytes_moved, F launch) {
     printf("  %-44s %8.1f GB/s (read+write)\n", name, (double)bytes_moved * reps / (ms * 1e-3) / 1e9);
 }
 
+
+// ---------------------------------------------------------------- butterfly ALU roofline
+// The product's own butterfly forms (csrc/modarith.hpp) on register-resident coefficients, no
+// memory traffic inside the loop: what the VALU alone can sustain, i.e. the ceiling the NTT kernels
+// are measured against.  One radix-8 pass (12 butterflies on 8 coefficients) per iteration.
+template <int FORM, bool SGPR_TW>   // FORM 0 exact, 1 fast, 2 16q-lazy (every 12th..: 5 of 12 butterflies subtract)
+__global__ void __launch_bounds__(512, 8) bf_kernel(uint64_t* out, const uint64_t* tw, uint64_t q, int iters) {
+    using namespace agx;
+    bf_consts k;
+    k.q = q;
+    k.nq = 0 - q;
+    k.m = FORM == 0 ? (q << 1) : (q << 2);
+    k.nm = opaque_sgpr64(0 - k.m);
+    k.one_a = opaque_one<0>();
+    k.one_b = opaque_one<1>();
+    final_consts fc;
+    fc.q2 = q << 1; fc.nq2 = opaque_sgpr64(0 - fc.q2); fc.q1 = q; fc.nq1 = opaque_sgpr64(0 - q);
+    fc.q8 = q << 3; fc.nq8 = opaque_sgpr64(0 - fc.q8);
+    uint64_t x[8];
+    for (int r = 0; r < 8; ++r) x[r] = (tw[(threadIdx.x * 8 + r) & 1023] >> 3);
+    // per-lane variant: 3 distinct twiddle pairs per thread stay in VGPRs (12 registers), as many as
+    // the kernels keep live at a time; wave-uniform variant: 7 pairs in SGPRs
+    constexpr int NTW = SGPR_TW ? 7 : 3;
+    uint64_t w[NTW], wp[NTW];
+    for (int j = 0; j < NTW; ++j) {
+        const size_t idx = SGPR_TW ? (size_t)(j * 2) : (size_t)((threadIdx.x & 63) * 16 + j * 2);
+        w[j] = tw[idx] % q;
+        wp[j] = tw[idx + 1];
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int stage = 0; stage < 3; ++stage) {
+            const int rb = 2 - stage;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1)), r1 = r0 | (1 << rb);
+                const int j = ((1 << stage) - 1 + (r0 >> (rb + 1))) % NTW;
+                if constexpr (FORM == 0) ct_butterfly_exact(x[r0], x[r1], w[j], wp[j], k);
+                else if constexpr (FORM == 1) ct_butterfly_fast<true>(x[r0], x[r1], w[j], wp[j], k);
+                else if (stage == 1 || (stage == 2 && b == 0)) ct_butterfly_lazy16<true, true>(x[r0], x[r1], w[j], wp[j], k, fc);   // 5 of 12
+                else ct_butterfly_lazy16<true, false>(x[r0], x[r1], w[j], wp[j], k, fc);
+            }
+        }
+        if constexpr (FORM == 2) {   // keep the values inside the form's range between iterations (not counted as butterfly work)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] &= 0x0fffffffffffffffull;
+        }
+    }
+    uint64_t acc = 0;
+    for (int r = 0; r < 8; ++r) acc ^= x[r];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int FORM, bool SGPR_TW>
+static void run_bf(const char* name, uint64_t* d_out, const uint64_t* d_tw, uint64_t q) {
+    const int iters = 2000, blocks = 256 * 4;   // 4 workgroups of 512 threads per CU = 8 waves/SIMD
+    bf_kernel<FORM, SGPR_TW><<<blocks, 512>>>(d_out, d_tw, q, 10);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int rep = 0; rep < 5; ++rep) bf_kernel<FORM, SGPR_TW><<<blocks, 512>>>(d_out, d_tw, q, iters);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bfs = 5.0 * blocks * 512.0 * iters * 12.0;           // lane-butterflies
+    const double per_s = bfs / (ms * 1e-3);
+    printf("  %-44s %7.2f G butterflies/s  -> n=4096 NTT ceiling %6.1f M NTT/s (%4.1f %% of the 8 TB/s roofline)\n", name,
+           per_s / 1e9, per_s / 24576.0 / 1e6, per_s / 24576.0 * 65536.0 / 8e12 * 100.0);
+}
+
 int main(int argc, char** argv) {
-    bool do_alu = true, do_bw = true;
-    if (argc > 1 && std::string(argv[1]) == "alu") do_bw = false;
-    if (argc > 1 && std::string(argv[1]) == "bw") do_alu = false;
+    bool do_alu = true, do_bw = true, do_bf = true;
+    if (argc > 1 && std::string(argv[1]) == "alu") do_bw = do_bf = false;
+    if (argc > 1 && std::string(argv[1]) == "bw") do_alu = do_bf = false;
+    if (argc > 1 && std::string(argv[1]) == "bf") do_alu = do_bw = false;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  clock=%d kHz  L2=%d  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate, prop.l2CacheSize, prop.sharedMemPerBlock);
     if (do_alu) {
@@ -241,6 +312,21 @@ int main(int argc, char** argv) {
             printf("\n");
         }
         CK(hipFree(d_out));
+    }
+    if (do_bf) {
+        const uint64_t q = 1152921504606830593ull;   // largest 60-bit prime = 1 mod 8192
+        std::vector<uint64_t> h(1024);
+        uint64_t st = 42;
+        for (auto& v : h) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = st; }
+        uint64_t *d_tw, *d_o;
+        CK(hipMalloc(&d_tw, h.size() * 8)); CK(hipMalloc(&d_o, 256 * 4 * 512 * 8));
+        CK(hipMemcpy(d_tw, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+        printf("butterfly ALU roofline: register-resident radix-8 passes, 8 waves/SIMD, no memory traffic in the loop\n");
+        run_bf<0, false>("exact form, per-lane twiddles", d_o, d_tw, q);
+        run_bf<1, false>("fast form (q<=2^61), per-lane twiddles", d_o, d_tw, q);
+        run_bf<2, false>("16q-lazy form (q<=2^60), per-lane twiddles", d_o, d_tw, q);
+        run_bf<2, true>("16q-lazy form, wave-uniform twiddles", d_o, d_tw, q);
+        CK(hipFree(d_tw)); CK(hipFree(d_o));
     }
     if (do_bw) {
         const size_t bytes = 2ull << 30;  // 2 GiB in + 2 GiB out: far beyond the 256 MiB Infinity Cache
