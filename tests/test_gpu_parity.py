@@ -437,6 +437,37 @@ def test_config4_shape_one_gpu_slice(agx, orc, dev):
     plan.close()
 
 
+def test_config4_full_per_gpu_slice_on_device(agx, orc, dev):
+    """BASELINE configs[3] at its real per-GPU size: n=16384, 8 primes, 65536/8 = 8192 polynomials
+    = 8 GiB in place.  Checked on the device (round trip; forward out of place == in place) and on a
+    few frames copied back for the oracle."""
+    import torch
+
+    n, primes, batch = 16384, 8, 8192
+    qs = agx.find_primes(60, n, primes)
+    plan = agx.Plan(n, qs)
+    total = primes * batch * n
+    a = dev.empty(total)
+    plan.fill_synthetic(a.data_ptr(), batch, 0, 7, dev.stream)
+    ref = a.clone()
+    fwd_oop = dev.empty(total)
+    plan.forward(a.data_ptr(), fwd_oop.data_ptr(), batch, dev.stream)      # fused-split kernels
+    plan.forward(a.data_ptr(), a.data_ptr(), batch, dev.stream)            # pair kernel, in place
+    dev.sync()
+    assert torch.equal(a, fwd_oop)
+    for p in (0, 5):
+        tw, pre = orc.make_tables(qs[p], plan.psi(p), n)
+        for f in (0, 4097, 8191):
+            lo = (p * batch + f) * n
+            x = ref[lo:lo + n].cpu().numpy().view(np.uint64)
+            assert np.array_equal(a[lo:lo + n].cpu().numpy().view(np.uint64), orc.forward(x, qs[p], tw, pre, n))
+    del fwd_oop
+    plan.inverse(a.data_ptr(), a.data_ptr(), batch, dev.stream)
+    dev.sync()
+    assert torch.equal(a, ref)
+    plan.close()
+
+
 def test_config5_polymul_32768(agx, orc, dev):
     """n=32768 full poly-mul (NTT -> pointwise -> INTT): convolution theorem checked through
     X^j * b = negacyclic shift of b, and against the oracle pipeline on one frame"""
