@@ -332,7 +332,11 @@ static int forward_common(const agx_ntt_plan* plan, const uint64_t* d_in, uint64
     fl.lazy_out = lazy_out;
     plan_view pv = view_of(plan);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (plan->variant != AGX_VARIANT_LDS_RADIX2) {   // forward-only layouts, where n has them
+    // forward-only layouts, where n has them.  n = 16384: measured faster than the one-workgroup-per-CU
+    // main kernel only while the launch is too small to fill the chip several times over (2,048 frames:
+    // +7..11 %; 8,192 frames and up: -4..6 %); n = 32768 out of place: always faster (+17 %).
+    const bool few_frames = batch * plan->num_primes < 4096;
+    if (plan->variant != AGX_VARIANT_LDS_RADIX2 && (plan->log_n != 14 || few_frames)) {
         if (d_in != d_out && plan->rb_oop.valid()) {
             pv.rb = plan->rb_oop;
             pv.tw_rb = plan->d_tw_rb_oop;
