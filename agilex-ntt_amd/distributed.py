@@ -11,7 +11,8 @@ class Group:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = device
-        if self.world > 1:
+        # AGX_FORCE_DIST=1 initialises the process group even for one rank (exercises the RCCL path on a single GPU)
+        if self.world > 1 or os.environ.get("AGX_FORCE_DIST") == "1":
             import torch.distributed as dist
 
             kwargs = {}

@@ -135,9 +135,9 @@ def main():
         step(args.warmup + i)
     ev1.record()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0     # this rank's K steps; the slowest rank defines the job (MAX below)
     grp.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration over the timed region
     elapsed = grp.max_over_ranks(elapsed)
 
