@@ -325,6 +325,40 @@ def test_large_frames_strided_in_and_out_of_place(agx, orc, dev, n):
     plan.close()
 
 
+def test_calls_are_graph_capturable(agx, orc, dev):
+    """the device-pointer calls allocate nothing and never synchronise, so a stream capture can
+    record them: forward + inverse captured once into a HIP graph, replayed on new data"""
+    import torch
+
+    n, batch = 4096, 8
+    q = agx.find_primes(60, n)[0]
+    plan = agx.Plan(n, [q])
+    tw, pre = orc.make_tables(q, plan.psi(0), n)
+    buf = dev.empty(batch * n)
+    mid = dev.empty(batch * n)
+    out = dev.empty(batch * n)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.forward(buf.data_ptr(), mid.data_ptr(), batch, side.cuda_stream)      # warm-up outside capture
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            s = torch.cuda.current_stream().cuda_stream
+            plan.forward(buf.data_ptr(), mid.data_ptr(), batch, s)
+            plan.inverse(mid.data_ptr(), out.data_ptr(), batch, s)
+    torch.cuda.current_stream().wait_stream(side)
+    rng = np.random.default_rng(4)
+    for _ in range(2):
+        x = rand_coeffs(rng, batch * n, q)
+        buf.copy_(torch.from_numpy(x.view(np.int64).copy()))
+        graph.replay()
+        dev.sync()
+        assert np.array_equal(dev.to_host(mid), orc.forward(x, q, tw, pre, n))
+        assert np.array_equal(dev.to_host(out), x)
+    plan.close()
+
+
 def test_empty_batch_and_errors(agx, dev):
     q = agx.find_primes(60, 4096)[0]
     plan = agx.Plan(4096, [q])
