@@ -49,7 +49,8 @@ struct barrett128 {
     uint64_t mu_hi, mu_lo;  // floor(2^128 / q)
 };
 
-// a, b < q < 2^62 -> a*b mod q in [0,q).  Quotient estimate is low by at most 3.
+// a*b mod q in [0,q) for a, b < q < 2^62, and also for a, b < 4q when q <= 2^60 (then a*b < 2^124 and
+// the quotient < 16q <= 2^64 still fit).  Quotient estimate is low by at most 3.
 __device__ __forceinline__ uint64_t mul_mod_barrett(uint64_t a, uint64_t b, const barrett128& k) {
     const uint64_t lo = a * b, hi = __umul64hi(a, b);
     const uint64_t est = hi * k.mu_hi + __umul64hi(hi, k.mu_lo) + __umul64hi(lo, k.mu_hi);

@@ -763,6 +763,9 @@ polymul_rb2(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint
     AGX_RB2_PROLOGUE;
     const prime_consts pc = consts[prime];
     const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
+    // q <= 2^60: the product below takes operands in [0,4q) (16 q^2 < 2^124, quotient < 16q <= 2^64), so
+    // both forward transforms may skip their last two conditional subtracts
+    f.lazy_out = F::LAZY16;
     uint64_t xa[C], xb[C];
 #pragma unroll
     for (int r = 0; r < C; ++r) xa[r] = a[base + f.tid + (uint32_t)r * T];
