@@ -113,3 +113,20 @@ def test_product_sources_never_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_bench_cpu_baseline_leg_runs(orc):
+    """bench.py's cpu_baseline leg (the oracle timed on host cores) on a tiny budget"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ["AGX_BENCH_CPU_THREADS"] = "2"
+    try:
+        r = bench.cpu_baseline(target_seconds=0.3)
+    finally:
+        del os.environ["AGX_BENCH_CPU_THREADS"]
+    assert r["kind"] == "port" and r["unit"] == "NTT/s" and r["cores"] == 2
+    assert r["value"] > 1000 and r["single_core_value"] > 500
+    assert bench.host_cores() >= 1
