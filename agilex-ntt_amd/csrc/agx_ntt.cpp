@@ -179,7 +179,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
 int check_call(const agx_ntt_plan* plan, const void* a, const void* b, uint64_t batch, int64_t prime_stride, int64_t poly_stride) {
     if (!plan || !a || !b) return AGX_ERR_NULL_POINTER;
     if (prime_stride < 0 || poly_stride < 0) return AGX_ERR_BAD_ARGUMENT;
-    if (batch > 0 && poly_stride < (int64_t)plan->n && batch > 1) return AGX_ERR_BAD_ARGUMENT;
+    if (batch > 1 && poly_stride < (int64_t)plan->n) return AGX_ERR_BAD_ARGUMENT;   // frames would overlap
     if ((batch << (plan->log_n > 14 ? plan->log_n - 14 : 0)) > 0x7fffffffull) return AGX_ERR_BAD_ARGUMENT;  // grid.x limit
     return AGX_OK;
 }
@@ -283,7 +283,11 @@ int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant) {
                     regblock_build_table(rb, w.data(), wp.data(), rb_pairs);
                 }
                 int rc = upload(&d_new[which], rb_pairs);
-                if (rc != AGX_OK) return rc;
+                if (rc != AGX_OK) {
+                    for (ulonglong2* d : d_new)
+                        if (d) (void)hipFree(d);
+                    return rc;
+                }
             }
             AGX_HIP(hipDeviceSynchronize());
             if (plan->d_tw_rb) (void)hipFree(plan->d_tw_rb);
