@@ -44,7 +44,7 @@ def test_golden_vectors(orc):
             assert [int(v) for v in y] == [int(v) for v in c["output"]]
 
 
-@pytest.mark.parametrize("n,bits", [(2, 20), (4, 30), (8, 61), (32, 30), (64, 60), (256, 61), (1024, 30), (2048, 60)])
+@pytest.mark.parametrize("n,bits", [(2, 20), (4, 30), (8, 61), (32, 30), (64, 60), (256, 61), (1024, 30), (2048, 60), (8192, 61)])
 def test_forward_matches_naive(orc, n, bits):
     q = orc.find_prime(bits, n)
     psi = orc.min_root(q, n)
