@@ -32,6 +32,7 @@ ABI = {
     "agx_ntt_strerror": (ctypes.c_char_p, [_int]),
     "agx_ntt_last_hip_error": (_int, []),
     "agx_ntt_device_count": (_int, [ctypes.POINTER(_int)]),
+    "agx_ntt_debug_set_trace_buffer": (_int, [_vp, _u64]),
     "agx_ntt_forward_host": (_int, [_p64, _p64, _p64, _p64, _p64, _p64, _u32, _u32]),
     "agx_ntt_forward_host_stream": (_int, [_vp, _p64, _p64, _p64, _u64]),
     "agx_ntt_plan_create": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64, _p64, _p64, _p64]),
@@ -116,6 +117,11 @@ def _np_ptr(a):
 
     assert isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(_p64)
+
+
+def debug_set_trace_buffer(d_buf, nbytes):
+    """Diagnostics (tools/timeline.py): where the registry's trace kernel writes its phase stamps; (0, 0) = off."""
+    _check(lib().agx_ntt_debug_set_trace_buffer(d_buf, nbytes), "debug_set_trace_buffer")
 
 
 def device_count():

@@ -219,6 +219,12 @@ int agx_ntt_device_count(int* count) {
     return AGX_OK;
 }
 
+int agx_ntt_debug_set_trace_buffer(void* d_buf, uint64_t bytes) {
+    if (!d_buf && bytes) return AGX_ERR_NULL_POINTER;
+    AGX_HIP(agx::regblock_set_trace(static_cast<uint64_t*>(d_buf), bytes / 128));
+    return AGX_OK;
+}
+
 int agx_ntt_plan_create(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, const uint64_t* moduli,
                         const uint64_t* twiddles, const uint64_t* precons,
                         const uint64_t* inv_twiddles, const uint64_t* inv_precons) {

@@ -359,6 +359,11 @@ constexpr int kOptPad = 1;       // padded LDS image, exchanges addressed base +
 constexpr int kOptSelect = 2;    // conditional subtract by compare + select instead of sign mask
 constexpr int kOptTwAhead = 32;   // per-lane passes: first three table entries fetched one pass early, the rest at pass start
 constexpr int kOptLazy16 = 16;   // q <= 2^60: 16q-lazy forward butterflies (conditional subtract on 5 of 12 stages)
+constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
+
+// where the kOptTrace kernels write: [wave][16] words, set through agx_ntt_debug_set_trace_buffer
+__device__ uint64_t* g_trace_buf = nullptr;
+__device__ uint64_t g_trace_waves = 0;
 
 // per-frame state shared by the second-generation kernels
 template <int L, int R, bool FAST, int OPT = 0, int S0 = 0>   // S0: stages already done before the resident transform
@@ -367,6 +372,29 @@ struct rb2_frame {
     static constexpr int C = G::C, T = G::T, NP = G::NP;
     static constexpr bool PAD = (OPT & kOptPad) != 0, SEL = (OPT & kOptSelect) != 0, LAZY16 = FAST && (OPT & kOptLazy16) != 0;
     static constexpr bool TWA = (OPT & kOptTwAhead) != 0 && R == 3;
+    static constexpr bool TRACE = (OPT & kOptTrace) != 0;
+    mutable uint64_t ts[12];
+    // phase stamp I, ordered after `anchor` is available and before anything that uses it afterwards
+    template <int I>
+    __device__ __forceinline__ void stamp(uint64_t& anchor) const {
+        if constexpr (TRACE) {
+            uint64_t t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(anchor) : : "memory");
+            ts[I] = t;
+        }
+    }
+    __device__ __forceinline__ void trace_flush() const {
+        if constexpr (TRACE) {
+            const uint64_t wave = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            if ((threadIdx.x & 63u) == 0 && g_trace_buf != nullptr && wave < g_trace_waves) {
+                uint64_t* dst = g_trace_buf + wave * 16;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) dst[i] = ts[i];
+                dst[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID: wave, simd, cu, sh, se
+                dst[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+            }
+        }
+    }
     // a per-lane pass with all R stages: the shape the look-ahead twiddle fetch handles
     static constexpr bool lane_full_pass(int p) { return p >= 0 && p < NP && G::rlo(p) < 6 && G::hi(p) - G::rlo(p) + 1 == R; }
     static constexpr uint32_t slab_elems = PAD ? (1u << L) + (1u << (L - 4)) : (1u << L);
@@ -483,6 +511,7 @@ struct rb2_frame {
             if constexpr (p > 0) {
                 if constexpr (p == P0) exchange_sync<p - 1>();
                 image_read<p>(x);
+                if constexpr (2 * p + 1 < 12) stamp<2 * p + 1>(x[C - 1]);
             }
             static_for<0, ns>([&](auto S) {
                 constexpr int rb = (hi - rlo) - S;        // gap bits descend: Cooley-Tukey
@@ -518,6 +547,7 @@ struct rb2_frame {
                     }
                 });
             });
+            if constexpr (2 * p + 2 < 12) stamp<2 * p + 2>(x[C - 1]);
             if constexpr (p < NP - 1) {
                 // A thread overwrites exactly the image words it read for this pass, so no other
                 // thread can still need them: only the read side of an exchange has to be ordered.
@@ -576,6 +606,18 @@ struct rb2_frame {
         const uint32_t own = img(tid << R);
         static_for<0, C>([&](auto Rr) { constexpr int r = Rr; slab[join(own, img((uint32_t)r))] = x[r]; });
         __builtin_amdgcn_wave_barrier();
+        if constexpr (TRACE) {
+            const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
+            uint64_t y[C];
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; y[r] = slab[join(s0, img(64u * (uint32_t)r))]; });
+            stamp<9>(y[C - 1]);
+            if (live) static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[base + e0 + 64u * (uint32_t)r] = y[r]; });
+            stamp<10>(y[0]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp<11>(y[0]);
+            trace_flush();
+            return;
+        }
         if (live) {
             const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
             static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[base + e0 + 64u * (uint32_t)r] = slab[join(s0, img(64u * (uint32_t)r))]; });
@@ -627,11 +669,17 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
         const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
         uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
         int64_t prime_stride, int64_t poly_stride, uint32_t lazy_out) {
+    uint64_t t_entry = 0;
+    if constexpr (((ARITH >> 1) & kOptTrace) != 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) : : "memory");
     AGX_RB2_PROLOGUE;
     f.lazy_out = lazy_out != 0;
     uint64_t x[C];
 #pragma unroll
     for (int r = 0; r < C; ++r) x[r] = in[base + f.tid + (uint32_t)r * T];
+    if constexpr (F::TRACE) {
+        f.ts[0] = t_entry;
+        f.template stamp<1>(x[C - 1]);
+    }
     f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
     f.store_last_layout(x, out, base, live);
 }
@@ -1031,6 +1079,7 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(27),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(39),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8>(50),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptTrace) << 1), 8>(70),   // diagnostics only
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(40),
@@ -1198,6 +1247,12 @@ hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint
 bool regblock_has_inverse(const regblock_layout& rb) {
     const rb_entry* e = rb_lookup(rb.config_id);
     return e && e->launch_inv;
+}
+
+hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &buf, sizeof(buf));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_trace_waves), &waves, sizeof(waves));
+    return e;
 }
 
 bool regblock_has_polymul(const regblock_layout& rb) {

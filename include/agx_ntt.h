@@ -53,6 +53,10 @@ typedef enum agx_status {
 const char* agx_ntt_strerror(int status);
 int agx_ntt_last_hip_error(void);     /* hipError_t of the last AGX_ERR_HIP on this thread */
 int agx_ntt_device_count(int* count); /* AGX_OK and *count = 0 when there is no GPU */
+/* Diagnostics for tools/timeline.py: the registry's trace kernel (AGX_VARIANT_REGBLOCK_BASE + 70) writes
+ * 16 u64 per wave (12 s_memtime phase stamps, HW_ID, XCC_ID) into this device buffer; NULL/0 turns it off.
+ * No reference counterpart. */
+int agx_ntt_debug_set_trace_buffer(void* d_buf, uint64_t bytes);
 
 /* ------------------------------------------------------------------------- */
 /* (1) One-shot host-pointer forward NTT.                                     */

@@ -299,7 +299,37 @@ static void run_bf(const char* name, uint64_t* d_out, const uint64_t* d_tw, uint
     }
 }
 
+// ---- workgroup dispatch: the NTT launch shape (16,384 workgroups x 512 threads, 34 KiB LDS) with waves
+// that only wait `ticks` of s_memtime.  Ideal duration = rounds x wait; the excess is what the dispatcher
+// needs to refill a slot after a workgroup retires.
+extern __shared__ unsigned char mb_dyn_lds[];
+__global__ void __launch_bounds__(512, 8) wait_kernel(uint64_t ticks, uint32_t* sink) {
+    const uint64_t t0 = __builtin_readcyclecounter();
+    if (ticks) {
+        while (__builtin_readcyclecounter() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    if (sink && threadIdx.x == 1023) *sink = mb_dyn_lds[0];
+}
+
+static void run_dispatch() {
+    const int lds = 34816, wgs = 16384;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wait_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    printf("workgroup dispatch, %d workgroups x 512 threads, %d B LDS (4 per CU, 16 rounds on 256 CUs)\n", wgs, lds);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (uint64_t ticks : {0ull, 5000ull, 10000ull, 25000ull, 50000ull}) {
+        for (int i = 0; i < 50; ++i) wait_kernel<<<wgs, 512, lds>>>(ticks, nullptr);
+        CK(hipEventRecord(e0));
+        const int reps = 50;
+        for (int i = 0; i < reps; ++i) wait_kernel<<<wgs, 512, lds>>>(ticks, nullptr);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        printf("  wave lifetime %6llu ticks: %8.1f us per launch = %6.3f us per round of 1024 workgroups\n", (unsigned long long)ticks, us, us / 16.0);
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "disp") { run_dispatch(); return 0; }
     bool do_alu = true, do_bw = true, do_bf = true;
     if (argc > 1 && std::string(argv[1]) == "alu") do_bw = do_bf = false;
     if (argc > 1 && std::string(argv[1]) == "bw") do_alu = do_bf = false;

@@ -22,6 +22,7 @@ ap.add_argument("--primes", type=int, default=4)
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--slabs", type=int, default=4)
 ap.add_argument("--op", choices=["fwd", "inv", "mul"], default="fwd")
+ap.add_argument("--launches", type=int, default=20, help="back-to-back launches per timing (20 = burst; 100+ shows the sustained clock)")
 ap.add_argument("--oop", action="store_true", help="time out of place (slab i -> slab i+1) instead of in place")
 args = ap.parse_args()
 N, P, B, SLABS = args.n, args.primes, args.batch, args.slabs
@@ -71,11 +72,11 @@ for rnd in range(5):
             run(slabs[i % SLABS], slabs[(i + 1) % SLABS] if args.oop else slabs[i % SLABS], slabs[(i + 1) % SLABS])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for i in range(20):
+        for i in range(args.launches):
             run(slabs[i % SLABS], slabs[(i + 1) % SLABS] if args.oop else slabs[i % SLABS], slabs[(i + 1) % SLABS])
         e1.record()
         torch.cuda.synchronize()
-        times[k].append(e0.elapsed_time(e1) / 20)
+        times[k].append(e0.elapsed_time(e1) / args.launches)
 print(f"{'id':>3} {'bit-exact':>9} {'min ms':>8} {'med ms':>8} {'MNTT/s':>8} {'GB/s':>8} {'%8TB/s':>7}")
 for k in ids:
     t = sorted(times[k])
