@@ -13,7 +13,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libagxntt.so")
+LIB_PATH = os.environ.get("AGX_NTT_LIB") or os.path.join(_HERE, "lib", "libagxntt.so")   # override: A/B builds in tools/
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 AGX_OK = 0

@@ -359,11 +359,22 @@ constexpr int kOptPad = 1;       // padded LDS image, exchanges addressed base +
 constexpr int kOptSelect = 2;    // conditional subtract by compare + select instead of sign mask
 constexpr int kOptTwAhead = 32;   // per-lane passes: first three table entries fetched one pass early, the rest at pass start
 constexpr int kOptLazy16 = 16;   // q <= 2^60: 16q-lazy forward butterflies (conditional subtract on 5 of 12 stages)
+constexpr int kOptPrio = 128;    // s_setprio 3 while a wave issues its frame loads (and, with kOptPrioStore, its stores)
+constexpr int kOptPrioStore = 256;
+constexpr int kOptPrioBarrier = 512;   // with kOptPrio: stay at priority until the frame's one s_barrier has been passed
+constexpr int kOptScalarBase = 1024;   // frame loads as (uniform pointer per register) + lane offset: no per-load VALU address arithmetic
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
 // where the kOptTrace kernels write: [wave][16] words, set through agx_ntt_debug_set_trace_buffer
 __device__ uint64_t* g_trace_buf = nullptr;
 __device__ uint64_t g_trace_waves = 0;
+
+// call-backs a kernel can thread into the forward passes (the streaming kernel uses both)
+struct rb2_no_hooks {
+    template <int p> __device__ __forceinline__ void before_image_write() const {}
+    template <int p> __device__ __forceinline__ void after_twiddle_issue() const {}
+    template <int p> __device__ __forceinline__ void after_exchange_sync() const {}
+};
 
 // per-frame state shared by the second-generation kernels
 template <int L, int R, bool FAST, int OPT = 0, int S0 = 0>   // S0: stages already done before the resident transform
@@ -373,7 +384,11 @@ struct rb2_frame {
     static constexpr bool PAD = (OPT & kOptPad) != 0, SEL = (OPT & kOptSelect) != 0, LAZY16 = FAST && (OPT & kOptLazy16) != 0;
     static constexpr bool TWA = (OPT & kOptTwAhead) != 0 && R == 3;
     static constexpr bool TRACE = (OPT & kOptTrace) != 0;
+    static constexpr bool PRIO = (OPT & kOptPrio) != 0, PRIO_STORE = (OPT & kOptPrioStore) != 0;
+    static constexpr bool PRIO_BARRIER = PRIO && (OPT & kOptPrioBarrier) != 0, SCALAR_BASE = (OPT & kOptScalarBase) != 0;
     mutable uint64_t ts[12];
+    uint64_t trace_wave = ~0ull;   // row of the trace buffer (default: launch-wide wave number)
+    bool trace_wait_stores = true; // stamp 11 after the stores have retired (not in the streaming kernel: that would drain its prefetch)
     // phase stamp I, ordered after `anchor` is available and before anything that uses it afterwards
     template <int I>
     __device__ __forceinline__ void stamp(uint64_t& anchor) const {
@@ -385,7 +400,8 @@ struct rb2_frame {
     }
     __device__ __forceinline__ void trace_flush() const {
         if constexpr (TRACE) {
-            const uint64_t wave = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            const uint64_t wave = trace_wave != ~0ull ? trace_wave
+                                                      : ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
             if ((threadIdx.x & 63u) == 0 && g_trace_buf != nullptr && wave < g_trace_waves) {
                 uint64_t* dst = g_trace_buf + wave * 16;
 #pragma unroll
@@ -489,6 +505,11 @@ struct rb2_frame {
     // writes the image
     template <int P0, int P1>
     __device__ __forceinline__ void forward_passes(uint64_t (&x)[C], const twpair* tbl) const {
+        rb2_no_hooks none;
+        forward_passes<P0, P1>(x, tbl, none);
+    }
+    template <int P0, int P1, class Hooks>
+    __device__ __forceinline__ void forward_passes(uint64_t (&x)[C], const twpair* tbl, Hooks& hooks) const {
         // look-ahead twiddles (TWA): entries 1..3 of the next per-lane pass are requested during the
         // last stage of the current pass, entries 4..7 at the start of their own pass, so the L2
         // latency of the per-lane table reads overlaps butterflies instead of stalling the wave
@@ -508,6 +529,7 @@ struct rb2_frame {
                 }
                 static_for<0, 4>([&](auto J) { constexpr int j = J; late[j] = t.col[(size_t)(j + 4) * t.hstride]; });
             }
+            hooks.template after_twiddle_issue<p>();
             if constexpr (p > 0) {
                 if constexpr (p == P0) exchange_sync<p - 1>();
                 image_read<p>(x);
@@ -551,8 +573,13 @@ struct rb2_frame {
             if constexpr (p < NP - 1) {
                 // A thread overwrites exactly the image words it read for this pass, so no other
                 // thread can still need them: only the read side of an exchange has to be ordered.
+                hooks.template before_image_write<p>();
                 image_write<p>(x);
-                if constexpr (p < P1 - 1) exchange_sync<p>();
+                if constexpr (p < P1 - 1) {
+                    exchange_sync<p>();
+                    if constexpr (PRIO_BARRIER && !G::exchange_is_wave_local(p)) __builtin_amdgcn_s_setprio(0);
+                    hooks.template after_exchange_sync<p>();
+                }
             }
         });
     }
@@ -560,6 +587,10 @@ struct rb2_frame {
     // last pass's layout (elements tid*C .. tid*C+C-1), fully reduced
     __device__ __forceinline__ void forward(uint64_t (&x)[C], const twpair* tbl) const {
         forward_passes<0, NP>(x, tbl);
+    }
+    template <class Hooks>
+    __device__ __forceinline__ void forward(uint64_t (&x)[C], const twpair* tbl, Hooks& hooks) const {
+        forward_passes<0, NP>(x, tbl, hooks);
     }
 
     // x in the last pass's layout, values in [0,m) -> inverse transform (Gentleman-Sande, gap bits
@@ -613,11 +644,12 @@ struct rb2_frame {
             stamp<9>(y[C - 1]);
             if (live) static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[base + e0 + 64u * (uint32_t)r] = y[r]; });
             stamp<10>(y[0]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (trace_wait_stores) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp<11>(y[0]);
             trace_flush();
             return;
         }
+        if constexpr (PRIO_STORE) __builtin_amdgcn_s_setprio(3);
         if (live) {
             const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
             static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[base + e0 + 64u * (uint32_t)r] = slab[join(s0, img(64u * (uint32_t)r))]; });
@@ -638,6 +670,7 @@ struct rb2_frame {
             if constexpr (!FAST) v = csub(v, k.m);    // exact form wants [0,2q); inputs may be < 4q
             slab[join(s0, img(64u * (uint32_t)r))] = v;
         }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_wave_barrier();
         const uint32_t own = img(tid << R);
 #pragma unroll
@@ -671,17 +704,120 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
         int64_t prime_stride, int64_t poly_stride, uint32_t lazy_out) {
     uint64_t t_entry = 0;
     if constexpr (((ARITH >> 1) & kOptTrace) != 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) : : "memory");
+    if constexpr (((ARITH >> 1) & kOptPrio) != 0) __builtin_amdgcn_s_setprio(3);
     AGX_RB2_PROLOGUE;
     f.lazy_out = lazy_out != 0;
     uint64_t x[C];
+    if constexpr (F::SCALAR_BASE) {
+        const uint64_t* src = in + base;     // wave-uniform
 #pragma unroll
-    for (int r = 0; r < C; ++r) x[r] = in[base + f.tid + (uint32_t)r * T];
+        for (int r = 0; r < C; ++r) x[r] = (src + (uint32_t)r * T)[f.tid];
+    } else {
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = in[base + f.tid + (uint32_t)r * T];
+    }
+    if constexpr (F::PRIO && !F::PRIO_BARRIER) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+    }
     if constexpr (F::TRACE) {
         f.ts[0] = t_entry;
         f.template stamp<1>(x[C - 1]);
     }
     f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
     f.store_last_layout(x, out, base, live);
+}
+
+template <class F>
+struct rb2_stream_hooks {
+    static constexpr int C = F::C, T = F::T;
+    const uint64_t* in;
+    uint64_t (&xn)[C];
+    const F& f;
+    volatile uint32_t* mailbox;
+    uint32_t slot, total, batch;
+    int64_t prime_stride, poly_stride;
+    uint32_t next;
+    template <int p> __device__ __forceinline__ void before_image_write() const {
+        if constexpr (p == 0) __builtin_amdgcn_s_barrier();     // barrier A: the image is free again
+    }
+    template <int p> __device__ __forceinline__ void after_exchange_sync() {
+        if constexpr (p == 0) next = (uint32_t)__builtin_amdgcn_readfirstlane((int)mailbox[slot]);
+    }
+    template <int p> __device__ __forceinline__ void after_twiddle_issue() const {
+        if constexpr (p == F::NP - 1) {
+            if (next < total) {     // wave-uniform
+                const int64_t nb = (int64_t)(next / batch) * prime_stride + (int64_t)(next % batch) * poly_stride;
+#pragma unroll
+                for (int r = 0; r < C; ++r) xn[r] = in[nb + f.tid + (uint32_t)r * T];
+            }
+        }
+    }
+};
+
+// Streaming forward kernel: a resident grid of workgroups (as many as fit the chip at once) draws frame
+// numbers from a ticket counter, so a workgroup slot is never empty while the dispatcher refills it
+// (tools/timeline.py: 5.7 of 8 wave slots occupied in fwd_rb2), and the next frame's coefficients are
+// requested while the last pass of the current frame still computes.  Per frame: barrier A (bare
+// s_barrier) before the first image write -- every wave has then finished reading the previous frame's
+// staged results -- and the usual barrier after it.  `ticket[0]` hands out frames (grid size + k),
+// `ticket[1]` counts retired workgroups; the last one to leave zeroes both for the next launch, so one
+// ticket pair must not be shared by launches that can run at the same time.
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+fwd_rb2_stream(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+               const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
+               uint32_t pairs_per_prime, uint32_t batch, uint32_t total,
+               int64_t prime_stride, int64_t poly_stride, uint32_t lazy_out, uint32_t* __restrict__ ticket) {
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;
+    constexpr int C = F::C, T = F::T;
+    F f;
+    f.tid = threadIdx.x;
+    f.blk = 0;
+    f.split_log = 0;
+    f.lazy_out = lazy_out != 0;
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(f.slab + F::slab_elems);   // two words behind the image
+
+
+    uint32_t fr = blockIdx.x;
+    if (fr >= total) return;
+    uint64_t xn[C];
+    {
+        const int64_t b0 = (int64_t)(fr / batch) * prime_stride + (int64_t)(fr % batch) * poly_stride;
+#pragma unroll
+        for (int r = 0; r < C; ++r) xn[r] = in[b0 + f.tid + (uint32_t)r * T];
+    }
+    rb2_stream_hooks<F> hooks{in, xn, f, mailbox, 0, total, batch, prime_stride, poly_stride, 0};
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t prime = fr / batch, poly = fr % batch;
+        const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
+        f.init_consts(consts[prime].q);
+        hooks.slot = it & 1u;
+        if (threadIdx.x == 0) mailbox[it & 1u] = atomicAdd(ticket, 1u) + gridDim.x;   // read by everyone after this frame's barrier
+        uint64_t x[C];
+        if constexpr (F::TRACE) {
+            uint64_t t_top;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_top) : : "memory");
+            f.ts[0] = t_top;
+            f.trace_wave = (uint64_t)fr * (T >> 6) + (threadIdx.x >> 6);
+            f.trace_wait_stores = false;
+        }
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = xn[r];
+        if constexpr (F::TRACE) f.template stamp<1>(x[C - 1]);
+        f.forward(x, tw_rb + (size_t)prime * pairs_per_prime, hooks);
+        f.store_last_layout(x, out, base, true);
+        fr = hooks.next;
+        if (fr >= total) break;
+    }
+    if (threadIdx.x == 0) {
+        if (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {     // last workgroup out: reset for the next launch
+            __threadfence();
+            ticket[0] = 0;
+            ticket[1] = 0;
+        }
+    }
 }
 
 // Forward transform of frames of 2^(L+S) coefficients by workgroups that keep 2^L of them: block
@@ -787,6 +923,7 @@ inv_rb2(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint6
         const prime_consts* __restrict__ consts, const twpair* __restrict__ itw_rb,
         uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
         int64_t prime_stride, int64_t poly_stride) {
+    if constexpr (((ARITH >> 1) & kOptPrio) != 0) __builtin_amdgcn_s_setprio(3);   // until the frame loads are out
     AGX_RB2_PROLOGUE;
     const prime_consts pc = consts[prime];
     const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
@@ -995,6 +1132,49 @@ constexpr rb_entry make_entry2(int id) {
                     &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>, 0, nullptr, false};
 }
 
+// prototype ticket pair of the streaming kernel (one per process: launches must not overlap)
+__device__ uint32_t g_stream_ticket[2] = {0, 0};
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t launch_rb2_stream_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    static int resident = 0;
+    static uint32_t* d_ticket = nullptr;
+    if (!resident) {
+        int dev = 0, cus = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void**>(&d_ticket), HIP_SYMBOL(g_stream_ticket));
+        if (e != hipSuccess) return e;
+        resident = cus * (MINW * 256 / G::T);   // workgroups the chip holds at MINW waves per SIMD
+    }
+    const uint64_t total = fl.batch * pv.num_primes;
+    if (total >= (1ull << 31)) return hipErrorInvalidValue;
+    const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
+    const unsigned grid = (unsigned)(total < (uint64_t)resident ? total : (uint64_t)resident);
+    hipLaunchKernelGGL((fwd_rb2_stream<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, out, pv.consts, pv.tw_rb,
+                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride,
+                       (uint32_t)(fl.lazy_out ? 1 : 0), d_ticket);
+    return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t init_rb2_stream_t() {
+    hipError_t e = init_rb2_t<L, R, 1, ARITH, MINW>();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_stream<L, R, ARITH, MINW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb2_lds_bytes<L, R, 1, ARITH>() + 16);
+    return e;
+}
+
+template <int L, int R, int ARITH, int MINW>
+constexpr rb_entry make_entry_stream(int id) {
+    rb_entry e = make_entry2<L, R, 1, ARITH, MINW>(id);
+    e.launch = &launch_rb2_stream_t<L, R, ARITH, MINW>;
+    e.init = &init_rb2_stream_t<L, R, ARITH, MINW>;
+    return e;
+}
+
 template <int L, int R, int PPB, int ARITH, int MINW, int S>
 hipError_t launch_rb2_split_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
@@ -1080,6 +1260,12 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(39),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8>(50),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptTrace) << 1), 8>(70),   // diagnostics only
+    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one launch at a time
+    // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
+    // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(90),
+    make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(40),
@@ -1142,7 +1328,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
         if (e && (split_for(*e) < 0 || e->arith > arith_level)) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
-        static const int kDefaults[] = {50, 39, 27, 28, 40, 29, 30, 41, 31, 32, 42, 33, 34, 43, 35, 36, 0, 1, 2, 3, 4};
+        static const int kDefaults[] = {90, 92, 91, 50, 39, 27, 28, 40, 29, 30, 41, 31, 32, 42, 33, 34, 43, 35, 36, 0, 1, 2, 3, 4};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
             if (c && split_for(*c) >= 0 && c->arith <= arith_level) { e = c; break; }

@@ -303,29 +303,65 @@ static void run_bf(const char* name, uint64_t* d_out, const uint64_t* d_tw, uint
 // that only wait `ticks` of s_memtime.  Ideal duration = rounds x wait; the excess is what the dispatcher
 // needs to refill a slot after a workgroup retires.
 extern __shared__ unsigned char mb_dyn_lds[];
-__global__ void __launch_bounds__(512, 8) wait_kernel(uint64_t ticks, uint32_t* sink) {
+// MODE 0: sleep; 1: multiply-add busy loop; 2: sleep, then the frame's stores; 3: the frame's loads, sleep, stores
+template <int MODE>
+__global__ void __launch_bounds__(512, 8) wait_kernel(uint64_t ticks, uint64_t* slab, uint32_t* sink) {
     const uint64_t t0 = __builtin_readcyclecounter();
-    if (ticks) {
-        while (__builtin_readcyclecounter() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    uint64_t* mine = slab + ((size_t)(blockIdx.x & 16383) << 12);
+    uint64_t v[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+    if constexpr (MODE == 3) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = mine[threadIdx.x + 512 * r];
     }
-    if (sink && threadIdx.x == 1023) *sink = mb_dyn_lds[0];
+    if (ticks) {
+        if constexpr (MODE == 1) {
+            uint64_t a = threadIdx.x, b = t0 | 1;
+            while (__builtin_readcyclecounter() - t0 < ticks) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) a = (uint64_t)(uint32_t)a * (uint32_t)b + a;
+            }
+            v[0] += a;
+        } else {
+            while (__builtin_readcyclecounter() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if constexpr (MODE >= 2) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) mine[threadIdx.x + 512 * r] = v[r] + 1;
+    }
+    if (sink && threadIdx.x == 1023) *sink = mb_dyn_lds[0] + (uint32_t)v[0];
 }
 
-static void run_dispatch() {
+template <int MODE>
+static void run_dispatch_mode(const char* name, uint64_t* slab) {
     const int lds = 34816, wgs = 16384;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wait_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    printf("workgroup dispatch, %d workgroups x 512 threads, %d B LDS (4 per CU, 16 rounds on 256 CUs)\n", wgs, lds);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wait_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (uint64_t ticks : {0ull, 5000ull, 10000ull, 25000ull, 50000ull}) {
-        for (int i = 0; i < 50; ++i) wait_kernel<<<wgs, 512, lds>>>(ticks, nullptr);
+    printf(" %s\n", name);
+    double base = 0;
+    for (uint64_t ticks : {0ull, 12500ull, 25000ull, 50000ull}) {
+        for (int i = 0; i < 30; ++i) wait_kernel<MODE><<<wgs, 512, lds>>>(ticks, slab, nullptr);
         CK(hipEventRecord(e0));
-        const int reps = 50;
-        for (int i = 0; i < reps; ++i) wait_kernel<<<wgs, 512, lds>>>(ticks, nullptr);
+        const int reps = 30;
+        for (int i = 0; i < reps; ++i) wait_kernel<MODE><<<wgs, 512, lds>>>(ticks, slab, nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps;
+        if (ticks == 0) base = us;
         printf("  wave lifetime %6llu ticks: %8.1f us per launch = %6.3f us per round of 1024 workgroups\n", (unsigned long long)ticks, us, us / 16.0);
     }
+    (void)base;
+}
+
+static void run_dispatch() {
+    printf("workgroup dispatch, 16384 workgroups x 512 threads, 34816 B LDS (4 per CU, 16 rounds on 256 CUs);\n"
+           "the slope between rows is the tick length, the intercept what a slot needs to turn around\n");
+    uint64_t* slab; CK(hipMalloc(&slab, (size_t)16384 * 32768)); CK(hipMemset(slab, 0, (size_t)16384 * 32768));
+    run_dispatch_mode<0>("sleeping waves", slab);
+    run_dispatch_mode<1>("waves in a multiply-add loop", slab);
+    run_dispatch_mode<2>("sleeping waves that store their 32 KiB frame before they end", slab);
+    run_dispatch_mode<3>("waves that load their frame, sleep, store it", slab);
+    CK(hipFree(slab));
 }
 
 int main(int argc, char** argv) {
