@@ -1259,7 +1259,7 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(27),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(39),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8>(50),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptTrace) << 1), 8>(70),   // diagnostics only
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptTrace) << 1), 8>(70),   // diagnostics only: id 90 + stamps
     make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one launch at a time
     // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)

@@ -30,6 +30,20 @@ if stats:
             avg_ns = float(r["AverageNs"])
     lines.append("")
 
+# the timed region = the last 100 dispatches of the kernel (bench.py's default --steps); the earlier ones are
+# the clock-ramp and warm-up launches, which run on a colder clock
+trace = glob.glob(os.path.join(root, "trace", "*", "*kernel_trace.csv"))
+if trace:
+    rows = [r for r in csv.DictReader(open(trace[0])) if want in r.get("Kernel_Name", "")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    if len(dur) >= 100:
+        last = dur[-100:]
+        avg_ns = sum(last) / len(last)
+        first = dur[:100]
+        lines += [f"`{want}*` dispatches: {len(dur)}; average of the LAST 100 (bench.py's timed steps) = **{avg_ns:.0f} ns**, "
+                  f"min {min(last)} / max {max(last)}; average of the first 100 after idle = {sum(first) / len(first):.0f} ns (clock ramp)", ""]
+
 counters = collections.OrderedDict()
 for d in ["pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_l2"]:
     f = glob.glob(os.path.join(root, d, "*", "*counter_collection.csv"))
