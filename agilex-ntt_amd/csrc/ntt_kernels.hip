@@ -1289,6 +1289,10 @@ const rb_entry kRbEntries[] = {
     make_entry_pair<13, 3, 0 | (kOptPad << 1), 8>(51),
     make_entry_pair<13, 3, 1 | ((kOptPad | kOptSelect) << 1), 8>(52),
     make_entry_pair<13, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(53),
+    // n = 32768 the same way: 1024 threads hold the frame (32 coefficients each), two 16384-halves in turn
+    make_entry_pair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 4>(54),
+    make_entry_pair<14, 4, 1 | ((kOptPad | kOptSelect) << 1), 4>(55),
+    make_entry_pair<14, 4, 0 | (kOptPad << 1), 4>(56),
 };
 
 const rb_entry* rb_lookup(int id) {
@@ -1349,7 +1353,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
 // invalid layout when n has none (the plan's main layout then serves forward calls too)
 regblock_layout regblock_choose_forward_only(uint32_t n, int arith_level, bool in_place) {
     static const int kOop[] = {46, 45, 44, 49, 48, 47};   // fused-split kernels: every block reads the whole frame
-    static const int kInPlace[] = {53, 52, 51};           // pair kernels: a workgroup owns the whole frame
+    static const int kInPlace[] = {53, 52, 51, 54, 55, 56};           // pair kernels: a workgroup owns the whole frame
     for (int id : kInPlace) {
         if (!in_place) break;
         regblock_layout rb = regblock_choose(n, id, arith_level);

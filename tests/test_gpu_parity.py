@@ -342,6 +342,25 @@ def test_large_frames_strided_in_and_out_of_place(agx, orc, dev, n):
     plan.close()
 
 
+@pytest.mark.parametrize("bits", [61, 62])
+@pytest.mark.parametrize("n", [16384, 32768])
+def test_large_frames_fast_and_exact_forms(agx, orc, dev, n, bits):
+    """the per-call-shape forward kernels of n=16384/32768 (pair kernels in place, fused-split out of
+    place) in their fast (61-bit q) and exact (62-bit q) arithmetic, against the oracle"""
+    batch, primes = 3, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes, inverse=False)
+    rng = np.random.default_rng(n + bits)
+    x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4 if bits < 62 else 3) for t in tabs])
+    want = _oracle_forward_rns(orc, x, tabs, n, batch)
+    d_in = dev.to_device(x)
+    d_out = dev.empty(x.size)
+    plan.forward(d_in.data_ptr(), d_out.data_ptr(), batch, dev.stream)     # out of place
+    assert np.array_equal(dev.to_host(d_out), want)
+    plan.forward(d_in.data_ptr(), d_in.data_ptr(), batch, dev.stream)      # in place
+    assert np.array_equal(dev.to_host(d_in), want)
+    plan.close()
+
+
 def test_calls_are_graph_capturable(agx, orc, dev):
     """the device-pointer calls allocate nothing and never synchronise, so a stream capture can
     record them: forward + inverse captured once into a HIP graph, replayed on new data"""
