@@ -32,6 +32,7 @@ struct agx_ntt_plan {
     ulonglong2* d_tw_rb_oop = nullptr;
     regblock_layout rb_fip;            // forward layout used when out == in (pair kernels), or invalid
     ulonglong2* d_tw_rb_fip = nullptr;
+    uint32_t* d_ticket = nullptr;      // {next frame, retired workgroups} of the streaming kernel (registry id 83), zero between launches
 };
 
 namespace {
@@ -71,12 +72,14 @@ plan_view view_of(const agx_ntt_plan* p) {
     v.rb = p->rb;
     v.tw_rb = p->d_tw_rb;
     v.itw_rb = p->d_itw_rb;
+    v.ticket = p->d_ticket;
     return v;
 }
 
 void free_plan(agx_ntt_plan* p) {
     if (!p) return;
     if (p->d_consts) (void)hipFree(p->d_consts);
+    if (p->d_ticket) (void)hipFree(p->d_ticket);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_itw) (void)hipFree(p->d_itw);
     if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
@@ -166,6 +169,11 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         if (p->rb_fip.valid()) regblock_build_table(p->rb_fip, twk, prek, fip_pairs);
     }
     if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
+    {
+        hipError_t te = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 2 * sizeof(uint32_t));
+        if (te == hipSuccess) te = hipMemset(p->d_ticket, 0, 2 * sizeof(uint32_t));
+        if (te != hipSuccess) { free_plan(p); return hip_fail(te); }
+    }
     if ((rc = upload(&p->d_tw, tw_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (itw && (rc = upload(&p->d_itw, itw_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && (rc = upload(&p->d_tw_rb, rb_pairs)) != AGX_OK) { free_plan(p); return rc; }

@@ -1132,29 +1132,24 @@ constexpr rb_entry make_entry2(int id) {
                     &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>, 0, nullptr, false};
 }
 
-// prototype ticket pair of the streaming kernel (one per process: launches must not overlap)
-__device__ uint32_t g_stream_ticket[2] = {0, 0};
-
 template <int L, int R, int ARITH, int MINW>
 hipError_t launch_rb2_stream_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     static int resident = 0;
-    static uint32_t* d_ticket = nullptr;
     if (!resident) {
         int dev = 0, cus = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void**>(&d_ticket), HIP_SYMBOL(g_stream_ticket));
         if (e != hipSuccess) return e;
         resident = cus * (MINW * 256 / G::T);   // workgroups the chip holds at MINW waves per SIMD
     }
     const uint64_t total = fl.batch * pv.num_primes;
-    if (total >= (1ull << 31)) return hipErrorInvalidValue;
+    if (total >= (1ull << 31) || !pv.ticket) return hipErrorInvalidValue;
     const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
     const unsigned grid = (unsigned)(total < (uint64_t)resident ? total : (uint64_t)resident);
     hipLaunchKernelGGL((fwd_rb2_stream<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, out, pv.consts, pv.tw_rb,
                        pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride,
-                       (uint32_t)(fl.lazy_out ? 1 : 0), d_ticket);
+                       (uint32_t)(fl.lazy_out ? 1 : 0), pv.ticket);
     return hipGetLastError();
 }
 
@@ -1260,7 +1255,7 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(39),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8>(50),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptTrace) << 1), 8>(70),   // diagnostics only: id 90 + stamps
-    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one launch at a time
+    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one stream per plan
     // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(90),

@@ -35,6 +35,7 @@ struct plan_view {
     regblock_layout rb;                    // forward register-blocked layout
     const ulonglong2* tw_rb = nullptr;     // [P][rb.pairs_per_prime]
     const ulonglong2* itw_rb = nullptr;    // same layout from the inverse tables, or null
+    uint32_t* ticket = nullptr;            // streaming kernel only: this plan's {frame ticket, retired workgroups} pair
 };
 
 struct frame_layout {
