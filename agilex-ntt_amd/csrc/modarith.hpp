@@ -317,6 +317,47 @@ __device__ __forceinline__ void gs_last_form(uint64_t& x, uint64_t& y, uint64_t 
     y = mul_shoup_form<FAST>(d, w1n, w1n_p, k);
 }
 
+// 16q-lazy Gentleman-Sande butterflies (q <= 2^60, so 16q <= 2^64).  y' = w d is below 4q whatever d is, so
+// only the sums grow: B is the compile-time bound, in units of q, that both inputs share (4, 8 or 16 -- a
+// butterfly's two inputs always have the same history).  Inputs at 16q are first brought below 8q; then
+// x' = x + y < 2b q <= 16q and d = x - y + b q in (0, 16q).  The caller tracks the bounds (gs_bound).
+template <bool SEL>
+__device__ __forceinline__ uint64_t csub_8q(uint64_t v, const final_consts& f) {
+    return SEL ? csub_select_c(v, f.nq8) : csub_sign_c(v, f.q8, f.nq8);
+}
+// bound of register r entering stage s of a pass whose registers all start below B0*q: the X output of a
+// stage doubles its (reduced) input bound, the Y output is below 4q
+constexpr int gs_bound(int B0, int s, int r) {
+    if (s == 0) return B0;
+    if ((r >> (s - 1)) & 1) return 4;
+    const int b = gs_bound(B0, s - 1, r);
+    return 2 * (b == 16 ? 8 : b);
+}
+template <int B, bool SEL>
+__device__ __forceinline__ void gs_butterfly_lazy16(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k, const final_consts& f) {
+    static_assert(B == 4 || B == 8 || B == 16, "bounds are 4q, 8q or 16q");
+    if constexpr (B == 16) {
+        x = csub_8q<SEL>(x, f);
+        y = csub_8q<SEL>(y, f);
+    }
+    const uint64_t s = x + y;
+    const uint64_t d = x + (B == 4 ? k.m : f.q8) - y;
+    y = mul_shoup_form<true>(d, w, wp, k);
+    x = s;
+}
+template <int B, bool SEL>
+__device__ __forceinline__ void gs_last_lazy16(uint64_t& x, uint64_t& y, uint64_t ninv, uint64_t ninv_p, uint64_t w1n, uint64_t w1n_p,
+                                               const bf_consts& k, const final_consts& f) {
+    if constexpr (B == 16) {
+        x = csub_8q<SEL>(x, f);
+        y = csub_8q<SEL>(y, f);
+    }
+    const uint64_t s = x + y;
+    const uint64_t d = x + (B == 4 ? k.m : f.q8) - y;
+    x = mul_shoup_form<true>(s, ninv, ninv_p, k);
+    y = mul_shoup_form<true>(d, w1n, w1n_p, k);
+}
+
 // [0,m) -> [0,q) after the inverse transform
 template <bool FAST, bool SEL = false>
 __device__ __forceinline__ uint64_t reduce_final_inv(uint64_t v, const bf_consts& k, const final_consts& f) {

@@ -362,6 +362,7 @@ constexpr int kOptLazy16 = 16;   // q <= 2^60: 16q-lazy forward butterflies (con
 constexpr int kOptPrio = 128;    // s_setprio 3 while a wave issues its frame loads (and, with kOptPrioStore, its stores)
 constexpr int kOptPrioStore = 256;
 constexpr int kOptPrioBarrier = 512;   // with kOptPrio: stay at priority until the frame's one s_barrier has been passed
+constexpr int kOptLazyInv = 2048;      // with kOptLazy16: inverse butterflies keep sums up to 16q (26 instead of 48 conditional subtracts per thread at n=4096)
 constexpr int kOptScalarBase = 1024;   // frame loads as (uniform pointer per register) + lane offset: no per-load VALU address arithmetic
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
@@ -386,6 +387,7 @@ struct rb2_frame {
     static constexpr bool TRACE = (OPT & kOptTrace) != 0;
     static constexpr bool PRIO = (OPT & kOptPrio) != 0, PRIO_STORE = (OPT & kOptPrioStore) != 0;
     static constexpr bool PRIO_BARRIER = PRIO && (OPT & kOptPrioBarrier) != 0, SCALAR_BASE = (OPT & kOptScalarBase) != 0;
+    static constexpr bool LAZY_INV = LAZY16 && (OPT & kOptLazyInv) != 0;
     mutable uint64_t ts[12];
     uint64_t trace_wave = ~0ull;   // row of the trace buffer (default: launch-wide wave number)
     bool trace_wait_stores = true; // stamp 11 after the stores have retired (not in the streaming kernel: that would drain its prefetch)
@@ -603,26 +605,45 @@ struct rb2_frame {
             tw_src<p> t;
             fetch<p>(t, itbl);
             if constexpr (p < NP - 1) image_read<p>(x);
+            // 16q-lazy form: every register of the first pass starts below 4q, of the later ones below 8q
+            constexpr int B0 = (p == NP - 1) ? 4 : 8;
             static_for<0, hi - rlo + 1>([&](auto S) {
                 constexpr int rb = S;                     // gap bits ascend
                 constexpr int kk = R - 1 - rb;
                 constexpr bool top_stage = (rlo + rb) == L - 1;
-#pragma unroll
-                for (int r0 = 0; r0 < C; ++r0) {
-                    if ((r0 >> rb) & 1) continue;
-                    const int r1 = r0 | (1 << rb);
+                static_for<0, C / 2>([&](auto Bf) {
+                    constexpr int b = Bf;
+                    constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
+                    constexpr int r1 = r0 | (1 << rb);
+                    constexpr int BND = gs_bound(B0, rb, r0);
                     if (top_stage && split_log == 0) {
-                        gs_last_form<FAST>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k);
+                        if constexpr (LAZY_INV) gs_last_lazy16<BND, SEL>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k, fc);
+                        else gs_last_form<FAST>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k);
                     } else {
                         const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
-                        gs_butterfly_form<FAST, SEL>(x[r0], x[r1], w.x, w.y, k);
+                        if constexpr (LAZY_INV) {
+                            gs_butterfly_lazy16<BND, SEL>(x[r0], x[r1], w.x, w.y, k, fc);
+                            if constexpr (top_stage) {      // a split transform's resident part: back below 4q for the final reduction
+                                x[r0] = csub_8q<SEL>(x[r0], fc);
+                                x[r0] = SEL ? csub_select(x[r0], k) : csub_sign(x[r0], k);
+                            }
+                        } else {
+                            gs_butterfly_form<FAST, SEL>(x[r0], x[r1], w.x, w.y, k);
+                        }
                     }
                     if constexpr (top_stage) {
                         x[r0] = reduce_final_inv<FAST, SEL>(x[r0], k, fc);
                         x[r1] = reduce_final_inv<FAST, SEL>(x[r1], k, fc);
                     }
-                }
+                });
             });
+            if constexpr (LAZY_INV && p > 0) {
+                // the next pass assumes 8q: bring the registers that ended at 16q back
+                static_for<0, C>([&](auto Rr) {
+                    constexpr int r = Rr;
+                    if constexpr (gs_bound(B0, hi - rlo + 1, r) == 16) x[r] = csub_8q<SEL>(x[r], fc);
+                });
+            }
             if constexpr (p > 0) {
                 image_write<p>(x);
                 exchange_sync<p - 1>();
@@ -1258,21 +1279,23 @@ const rb_entry kRbEntries[] = {
     make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one stream per plan
     // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(90),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv) << 1), 8>(90),
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(40),
+    make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv) << 1), 8>(61),
     make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
     make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31),
-    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(41),
+    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv) << 1), 8>(41),
     make_entry2<13, 3, 1, 0 | (kOptPad << 1), 8>(34),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(33),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(42),
+    make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv) << 1), 8>(64),
     make_entry2<14, 4, 1, 0 | (kOptPad << 1), 4>(36),
     make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect) << 1), 4>(35),
-    make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 4>(43),
+    make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv) << 1), 4>(43),
     // n = 16384 / 32768 as 2 / 4 resident blocks of 8192 (8 waves/SIMD) with fused leading stages
     make_entry_split<13, 3, 1, 0 | (kOptPad << 1), 8, 1>(44),
     make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8, 1>(45),
@@ -1327,7 +1350,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
         if (e && (split_for(*e) < 0 || e->arith > arith_level)) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
-        static const int kDefaults[] = {90, 92, 91, 50, 39, 27, 28, 40, 29, 30, 41, 31, 32, 42, 33, 34, 43, 35, 36, 0, 1, 2, 3, 4};
+        static const int kDefaults[] = {90, 92, 91, 50, 39, 27, 28, 61, 40, 29, 30, 41, 31, 32, 64, 42, 33, 34, 43, 35, 36, 0, 1, 2, 3, 4};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
             if (c && split_for(*c) >= 0 && c->arith <= arith_level) { e = c; break; }

@@ -227,6 +227,27 @@ def test_extreme_coefficients(agx, orc, dev, bits):
     plan.close()
 
 
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("bits", [60, 61])
+def test_inverse_extreme_inputs(agx, orc, dev, n, bits):
+    """the inverse's lazy sums at their worst: every input 4q-1 (the largest value the contract admits),
+    q-1, alternating 4q-1 / 0, under the largest 60-bit (16q-lazy inverse) and 61-bit (fast form) moduli;
+    expected = the oracle's inverse of the residues"""
+    q = orc.find_prime(bits, n)
+    psi = orc.min_root(q, n)
+    plan = agx.Plan(n, [q], psi=[psi])
+    top = 4 * q - 1
+    x = np.concatenate([np.full(n, top, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64),
+                        np.where(np.arange(n) % 2 == 0, np.uint64(top), np.uint64(0)),
+                        np.where(np.arange(n) % 3 == 0, np.uint64(top), np.uint64(top - q))])
+    itw = orc.make_inv_tables(q, psi, n)[0]
+    want = orc.inverse(x % np.uint64(q), q, itw, n)
+    d = dev.to_device(x)
+    plan.inverse(d.data_ptr(), d.data_ptr(), 4, dev.stream)
+    assert np.array_equal(dev.to_host(d), want)
+    plan.close()
+
+
 @pytest.mark.parametrize("n", ALL_SIZES)
 def test_inverse_round_trip_and_oracle(agx, orc, dev, n):
     bits = 30 if n == 1024 else 60
