@@ -957,6 +957,47 @@ inv_rb2(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint6
     }
 }
 
+// Inverse of frames of 2^(L+1) coefficients in one pass (the mirror of fwd_rb2_pair): one workgroup inverts
+// the frame's two resident halves in turn, the first waiting in registers, and then runs the transform's
+// last stage (gap 2^L, n^-1 folded in) on the register pairs -- instead of a separate inv_global_stage
+// pass over HBM.  Everything is loaded before anything is stored, so in place is safe.
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+inv_rb2_pair(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint64_t* __restrict__ out,
+             const prime_consts* __restrict__ consts, const twpair* __restrict__ itw_rb,
+             uint32_t pairs_per_prime, int64_t prime_stride, int64_t poly_stride) {
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;
+    constexpr int C = F::C, T = F::T;
+    constexpr bool FAST = (ARITH & 1) == 1;
+    F f;
+    f.tid = threadIdx.x;
+    const uint32_t prime = blockIdx.y;
+    f.split_log = 1;
+    const prime_consts pc = consts[prime];
+    f.init_consts(pc.q);
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
+    const int64_t frame = (int64_t)prime * prime_stride + (int64_t)blockIdx.x * poly_stride;
+    const twpair* itbl = itw_rb + (size_t)prime * pairs_per_prime;
+
+    uint64_t lo[C], hi[C];
+    f.blk = 0;
+    f.load_last_layout(lo, in, in2, bk, frame);
+    f.inverse(lo, itbl, pc);
+    __syncthreads();   // the second half's staging overwrites image words other waves may still be reading
+    f.blk = 1;
+    f.load_last_layout(hi, in, in2, bk, frame + (1 << L));
+    f.inverse(hi, itbl, pc);
+    static_for<0, C>([&](auto Rr) {
+        constexpr int r = Rr;
+        gs_last_form<FAST>(lo[r], hi[r], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, f.k);
+        lo[r] = reduce_final_inv<FAST, F::SEL>(lo[r], f.k, f.fc);
+        hi[r] = reduce_final_inv<FAST, F::SEL>(hi[r], f.k, f.fc);
+    });
+    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[frame + f.tid + (uint32_t)r * T] = lo[r]; });
+    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[frame + (1 << L) + f.tid + (uint32_t)r * T] = hi[r]; });
+}
+
 // c = INTT(NTT(a) o NTT(b)) for one frame without leaving the chip: both forward transforms end in
 // the same register layout, the product is taken there, and the inverse starts from it (no staging
 // through the image at either seam).  HBM traffic 24n bytes per product.
@@ -1050,6 +1091,8 @@ struct rb_entry {
     int fused_split;   // S > 0: `launch` is only for out != in and computes the S leading stages itself (n = 2^(log_local+S))
     hipError_t (*launch_fused)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     bool fused_in_place_ok;   // launch_fused loads a whole frame before it stores any of it
+    // n = 2^(log_local+1): whole inverse (both resident halves + the last stage) in one launch, or null
+    hipError_t (*launch_inv_pair)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
 };
 
 template <int L, int R, bool col_major = false>
@@ -1230,6 +1273,34 @@ hipError_t init_rb2_pair_t() {
     return e;
 }
 
+template <int L, int R, int ARITH, int MINW>
+hipError_t launch_inv_rb2_pair_t(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>();
+    dim3 grid((unsigned)fl.batch, pv.num_primes);
+    hipLaunchKernelGGL((inv_rb2_pair<L, R, ARITH, MINW>), grid, dim3(G::T), lds, s, in, in2, out, pv.consts, pv.itw_rb,
+                       pv.rb.pairs_per_prime, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t init_rb2_invpair_t() {
+    hipError_t e = init_rb2_t<L, R, 1, ARITH, MINW>();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2_pair<L, R, ARITH, MINW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb2_lds_bytes<L, R, 1, ARITH>());
+    return e;
+}
+
+// a second-generation entry whose inverse at n = 2^(L+1) is the one-launch pair kernel
+template <int L, int R, int ARITH, int MINW>
+constexpr rb_entry make_entry2_invpair(int id) {
+    rb_entry e = make_entry2<L, R, 1, ARITH, MINW>(id);
+    e.init = &init_rb2_invpair_t<L, R, ARITH, MINW>;
+    e.launch_inv_pair = &launch_inv_rb2_pair_t<L, R, ARITH, MINW>;
+    return e;
+}
+
 // n = 2^(L+1) with one workgroup per frame transforming its two halves in turn (in-place safe);
 // the inverse of such a plan runs on the 2^L blocks + inv_global_stage
 template <int L, int R, int ARITH, int MINW>
@@ -1293,9 +1364,9 @@ const rb_entry kRbEntries[] = {
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(33),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(42),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv) << 1), 8>(64),
-    make_entry2<14, 4, 1, 0 | (kOptPad << 1), 4>(36),
-    make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect) << 1), 4>(35),
-    make_entry2<14, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv) << 1), 4>(43),
+    make_entry2_invpair<14, 4, 0 | (kOptPad << 1), 4>(36),
+    make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect) << 1), 4>(35),
+    make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv) << 1), 4>(43),
     // n = 16384 / 32768 as 2 / 4 resident blocks of 8192 (8 waves/SIMD) with fused leading stages
     make_entry_split<13, 3, 1, 0 | (kOptPad << 1), 8, 1>(44),
     make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8, 1>(45),
@@ -1471,6 +1542,7 @@ bool regblock_has_polymul(const regblock_layout& rb) {
 hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     const rb_entry* e = rb_lookup(pv.rb.config_id);
     if (!e || !e->launch_inv || !pv.itw_rb) return hipErrorInvalidValue;
+    if (pv.rb.log_split == 1 && e->launch_inv_pair) return e->launch_inv_pair(pv, in, in2, out, fl, s);
     hipError_t err = e->launch_inv(pv, in, in2, out, fl, s);
     if (err != hipSuccess) return err;
     for (int st = pv.rb.log_split - 1; st >= 0; --st) {   // stages with a gap wider than the resident block

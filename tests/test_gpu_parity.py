@@ -248,6 +248,27 @@ def test_inverse_extreme_inputs(agx, orc, dev, n, bits):
     plan.close()
 
 
+@pytest.mark.parametrize("n", [4096, 16384, 32768])
+@pytest.mark.parametrize("bits", [61, 62])
+def test_inverse_fast_and_exact_forms(agx, orc, dev, n, bits):
+    """inverse kernels in their fast (61-bit q) and exact (62-bit q) arithmetic -- at n=32768 the one-launch
+    pair kernel -- against the oracle's inverse, in place and out of place, plus the round trip"""
+    batch, primes = 3, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
+    rng = np.random.default_rng(n * 3 + bits)
+    r = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+    want = np.concatenate([orc.inverse(r[p * batch * n:(p + 1) * batch * n], tabs[p][0],
+                                       orc.make_inv_tables(tabs[p][0], tabs[p][1], n)[0], n) for p in range(primes)])
+    d_r, d_o = dev.to_device(r), dev.empty(r.size)
+    plan.inverse(d_r.data_ptr(), d_o.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_o), want)
+    plan.inverse(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_r), want)
+    plan.forward(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_r), r)
+    plan.close()
+
+
 @pytest.mark.parametrize("n", ALL_SIZES)
 def test_inverse_round_trip_and_oracle(agx, orc, dev, n):
     bits = 30 if n == 1024 else 60
