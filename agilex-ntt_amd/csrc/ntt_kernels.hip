@@ -363,6 +363,7 @@ constexpr int kOptPrio = 128;    // s_setprio 3 while a wave issues its frame lo
 constexpr int kOptPrioStore = 256;
 constexpr int kOptPrioBarrier = 512;   // with kOptPrio: stay at priority until the frame's one s_barrier has been passed
 constexpr int kOptLazyInv = 2048;      // with kOptLazy16: inverse butterflies keep sums up to 16q (26 instead of 48 conditional subtracts per thread at n=4096)
+constexpr int kOptTwAheadInv = 4096;   // inverse: the next per-lane pass's first-stage twiddles (entries 4..7) fetched during the current pass's last stage
 constexpr int kOptScalarBase = 1024;   // frame loads as (uniform pointer per register) + lane offset: no per-load VALU address arithmetic
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
@@ -388,6 +389,7 @@ struct rb2_frame {
     static constexpr bool PRIO = (OPT & kOptPrio) != 0, PRIO_STORE = (OPT & kOptPrioStore) != 0;
     static constexpr bool PRIO_BARRIER = PRIO && (OPT & kOptPrioBarrier) != 0, SCALAR_BASE = (OPT & kOptScalarBase) != 0;
     static constexpr bool LAZY_INV = LAZY16 && (OPT & kOptLazyInv) != 0;
+    static constexpr bool TWA_INV = (OPT & kOptTwAheadInv) != 0 && R == 3;
     mutable uint64_t ts[12];
     uint64_t trace_wave = ~0ull;   // row of the trace buffer (default: launch-wide wave number)
     bool trace_wait_stores = true; // stamp 11 after the stores have retired (not in the streaming kernel: that would drain its prefetch)
@@ -599,9 +601,12 @@ struct rb2_frame {
     // ascending), x in pass-0 layout, fully reduced.  With split_log = 0 the top stage also
     // multiplies by n^-1; otherwise inv_global_stage finishes the transform.
     __device__ __forceinline__ void inverse(uint64_t (&x)[C], const twpair* itbl, const prime_consts& pc) const {
+        twpair first[4];     // TWA_INV: entries 4..7 of the pass about to start (its first stage), fetched one pass early
         static_for<0, NP>([&](auto Q) {
             constexpr int p = NP - 1 - Q;
             constexpr int rlo = G::rlo(p), hi = G::hi(p);
+            constexpr bool twa_have = TWA_INV && p < NP - 1 && lane_full_pass(p) && lane_full_pass(p + 1);   // the previous pass fetched `first`
+            constexpr bool twa_next = TWA_INV && p > 0 && lane_full_pass(p) && lane_full_pass(p - 1);
             tw_src<p> t;
             fetch<p>(t, itbl);
             if constexpr (p < NP - 1) image_read<p>(x);
@@ -611,6 +616,13 @@ struct rb2_frame {
                 constexpr int rb = S;                     // gap bits ascend
                 constexpr int kk = R - 1 - rb;
                 constexpr bool top_stage = (rlo + rb) == L - 1;
+                if constexpr (twa_next && S == hi - rlo) {
+                    // `first` is free: this pass's first stage is long done
+                    constexpr int pn = p - 1;
+                    const twpair* ncol = itbl + G::table_off(pn) * (1u << split_log) + (size_t)blk * G::H(pn) + (tid >> G::rlo(pn));
+                    const uint32_t nstride = (uint32_t)G::H(pn) << split_log;
+                    static_for<0, 4>([&](auto J) { constexpr int jj = J; first[jj] = ncol[(size_t)(jj + 4) * nstride]; });
+                }
                 static_for<0, C / 2>([&](auto Bf) {
                     constexpr int b = Bf;
                     constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
@@ -620,7 +632,10 @@ struct rb2_frame {
                         if constexpr (LAZY_INV) gs_last_lazy16<BND, SEL>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k, fc);
                         else gs_last_form<FAST>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k);
                     } else {
-                        const twpair w = twiddle<p>(t, (1 << kk) + (r0 >> (rb + 1)));
+                        constexpr int j = (1 << kk) + (r0 >> (rb + 1));
+                        twpair w;
+                        if constexpr (twa_have && j >= 4) w = first[j - 4];
+                        else w = twiddle<p>(t, j);
                         if constexpr (LAZY_INV) {
                             gs_butterfly_lazy16<BND, SEL>(x[r0], x[r1], w.x, w.y, k, fc);
                             if constexpr (top_stage) {      // a split transform's resident part: back below 4q for the final reduction
@@ -1350,7 +1365,7 @@ const rb_entry kRbEntries[] = {
     make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one stream per plan
     // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv) << 1), 8>(90),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv) << 1), 8>(90),
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
