@@ -384,7 +384,7 @@ struct rb2_frame {
     using G = rb2_geom<L, R>;
     static constexpr int C = G::C, T = G::T, NP = G::NP;
     static constexpr bool PAD = (OPT & kOptPad) != 0, SEL = (OPT & kOptSelect) != 0, LAZY16 = FAST && (OPT & kOptLazy16) != 0;
-    static constexpr bool TWA = (OPT & kOptTwAhead) != 0 && R == 3;
+    static constexpr bool TWA = (OPT & kOptTwAhead) != 0 && R >= 3;
     static constexpr bool TRACE = (OPT & kOptTrace) != 0;
     static constexpr bool PRIO = (OPT & kOptPrio) != 0, PRIO_STORE = (OPT & kOptPrioStore) != 0;
     static constexpr bool PRIO_BARRIER = PRIO && (OPT & kOptPrioBarrier) != 0, SCALAR_BASE = (OPT & kOptScalarBase) != 0;
@@ -514,10 +514,10 @@ struct rb2_frame {
     }
     template <int P0, int P1, class Hooks>
     __device__ __forceinline__ void forward_passes(uint64_t (&x)[C], const twpair* tbl, Hooks& hooks) const {
-        // look-ahead twiddles (TWA): entries 1..3 of the next per-lane pass are requested during the
-        // last stage of the current pass, entries 4..7 at the start of their own pass, so the L2
+        // look-ahead twiddles (TWA): entries 1..C/2-1 of the next per-lane pass are requested during the
+        // last stage of the current pass, entries C/2..C-1 at the start of their own pass, so the L2
         // latency of the per-lane table reads overlaps butterflies instead of stalling the wave
-        twpair ahead[4];
+        twpair ahead[C / 2];      // entries 1 .. C/2-1 (all stages but the pass's last)
         static_for<P0, P1>([&](auto P) {
             constexpr int p = P;
             constexpr int rlo = G::rlo(p), hi = G::hi(p), ns = hi - rlo + 1;
@@ -526,12 +526,12 @@ struct rb2_frame {
             constexpr bool twa_next = TWA && p + 1 < P1 && lane_full_pass(p + 1);
             tw_src<p> t;
             fetch<p>(t, tbl);
-            twpair late[4];
+            twpair late[C / 2];   // entries C/2 .. C-1 (the pass's last stage)
             if constexpr (twa_here) {
                 if constexpr (!twa_prev) {
-                    static_for<1, 4>([&](auto J) { constexpr int j = J; ahead[j] = t.col[(size_t)j * t.hstride]; });
+                    static_for<1, C / 2>([&](auto J) { constexpr int j = J; ahead[j] = t.col[(size_t)j * t.hstride]; });
                 }
-                static_for<0, 4>([&](auto J) { constexpr int j = J; late[j] = t.col[(size_t)(j + 4) * t.hstride]; });
+                static_for<0, C / 2>([&](auto J) { constexpr int j = J; late[j] = t.col[(size_t)(j + C / 2) * t.hstride]; });
             }
             hooks.template after_twiddle_issue<p>();
             if constexpr (p > 0) {
@@ -548,7 +548,7 @@ struct rb2_frame {
                     constexpr int pn = p + 1;
                     const twpair* ncol = tbl + G::table_off(pn) * (1u << split_log) + (size_t)blk * G::H(pn) + (tid >> G::rlo(pn));
                     const uint32_t nstride = (uint32_t)G::H(pn) << split_log;
-                    static_for<1, 4>([&](auto J) { constexpr int j = J; ahead[j] = ncol[(size_t)j * nstride]; });
+                    static_for<1, C / 2>([&](auto J) { constexpr int j = J; ahead[j] = ncol[(size_t)j * nstride]; });
                 }
                 static_for<0, C / 2>([&](auto B) {
                     // B-th butterfly of the stage: insert a 0 at register bit rb
@@ -557,8 +557,8 @@ struct rb2_frame {
                     constexpr int r1 = r0 | (1 << rb);
                     constexpr int j = (1 << kk) + (r0 >> (rb + 1));
                     twpair w;
-                    if constexpr (twa_here && j < 4) w = ahead[j];
-                    else if constexpr (twa_here) w = late[j - 4];
+                    if constexpr (twa_here && j < C / 2) w = ahead[j];
+                    else if constexpr (twa_here) w = late[j - C / 2];
                     else w = twiddle<p>(t, j);
                     constexpr int stage = S0 + L - 1 - (rlo + rb);   // position in the whole transform
                     butterfly<stage>(x[r0], x[r1], w);
@@ -1381,7 +1381,7 @@ const rb_entry kRbEntries[] = {
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv) << 1), 8>(64),
     make_entry2_invpair<14, 4, 0 | (kOptPad << 1), 4>(36),
     make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect) << 1), 4>(35),
-    make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv) << 1), 4>(43),
+    make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead) << 1), 4>(43),
     // n = 16384 / 32768 as 2 / 4 resident blocks of 8192 (8 waves/SIMD) with fused leading stages
     make_entry_split<13, 3, 1, 0 | (kOptPad << 1), 8, 1>(44),
     make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8, 1>(45),
