@@ -376,6 +376,7 @@ struct rb2_no_hooks {
     template <int p> __device__ __forceinline__ void before_image_write() const {}
     template <int p> __device__ __forceinline__ void after_twiddle_issue() const {}
     template <int p> __device__ __forceinline__ void after_exchange_sync() const {}
+    template <int p, bool last_stage_of_pass, int b> __device__ __forceinline__ void after_butterfly() const {}
 };
 
 // per-frame state shared by the second-generation kernels
@@ -571,6 +572,7 @@ struct rb2_frame {
                             x[r1] = reduce_final<FAST, SEL>(x[r1], k, fc, lazy_out);
                         }
                     }
+                    hooks.template after_butterfly<p, S == ns - 1, b>();
                 });
             });
             if constexpr (2 * p + 2 < 12) stamp<2 * p + 2>(x[C - 1]);
@@ -764,29 +766,48 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     f.store_last_layout(x, out, base, live);
 }
 
-template <class F>
+template <class F, int PF>
 struct rb2_stream_hooks {
     static constexpr int C = F::C, T = F::T;
     const uint64_t* in;
     uint64_t (&xn)[C];
     const F& f;
     volatile uint32_t* mailbox;
+    uint32_t* ticket;
     uint32_t slot, total, batch;
     int64_t prime_stride, poly_stride;
     uint32_t next;
+    uint32_t pending;     // thread 0: the ticket drawn one frame ahead (TK == 1)
     template <int p> __device__ __forceinline__ void before_image_write() const {
         if constexpr (p == 0) __builtin_amdgcn_s_barrier();     // barrier A: the image is free again
     }
     template <int p> __device__ __forceinline__ void after_exchange_sync() {
         if constexpr (p == 0) next = (uint32_t)__builtin_amdgcn_readfirstlane((int)mailbox[slot]);
     }
-    template <int p> __device__ __forceinline__ void after_twiddle_issue() const {
-        if constexpr (p == F::NP - 1) {
+
+    template <int p> __device__ __forceinline__ void after_twiddle_issue() {
+        if constexpr (PF == 1 && p == F::NP - 1) {
+            if (f.tid == 0) pending = atomicAdd(ticket, 1u);    // for the frame after next; back long before the loop top
+        }
+        if constexpr (PF == 0 && p == F::NP - 1) {
             if (next < total) {     // wave-uniform
                 const int64_t nb = (int64_t)(next / batch) * prime_stride + (int64_t)(next % batch) * poly_stride;
 #pragma unroll
                 for (int r = 0; r < C; ++r) xn[r] = in[nb + f.tid + (uint32_t)r * T];
             }
+        }
+    }
+    // PF 1: two registers of the next frame after each butterfly of the last pass's last stage, into the
+    // VGPRs its twiddle has just left (a frame past the end re-reads the last frame: no branch, so the
+    // fences below fix where the loads are issued)
+    template <int p, bool last_stage_of_pass, int b> __device__ __forceinline__ void after_butterfly() const {
+        if constexpr (PF == 1 && p == F::NP - 1 && last_stage_of_pass) {
+            const uint32_t fn = next < total ? next : total - 1;
+            const uint64_t* src = in + (int64_t)(fn / batch) * prime_stride + (int64_t)(fn % batch) * poly_stride;
+            asm volatile("" ::: "memory");
+            xn[2 * b] = (src + (uint32_t)(2 * b) * T)[f.tid];
+            xn[2 * b + 1] = (src + (uint32_t)(2 * b + 1) * T)[f.tid];
+            asm volatile("" ::: "memory");
         }
     }
 };
@@ -799,7 +820,7 @@ struct rb2_stream_hooks {
 // staged results -- and the usual barrier after it.  `ticket[0]` hands out frames (grid size + k),
 // `ticket[1]` counts retired workgroups; the last one to leave zeroes both for the next launch, so one
 // ticket pair must not be shared by launches that can run at the same time.
-template <int L, int R, int ARITH, int MINW>
+template <int L, int R, int ARITH, int MINW, int PF>
 __global__ void __launch_bounds__((1 << (L - R)), MINW)
 fwd_rb2_stream(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
@@ -824,13 +845,20 @@ fwd_rb2_stream(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
 #pragma unroll
         for (int r = 0; r < C; ++r) xn[r] = in[b0 + f.tid + (uint32_t)r * T];
     }
-    rb2_stream_hooks<F> hooks{in, xn, f, mailbox, 0, total, batch, prime_stride, poly_stride, 0};
+    rb2_stream_hooks<F, PF> hooks{in, xn, f, mailbox, ticket, 0, total, batch, prime_stride, poly_stride, 0, 0};
+    if constexpr (PF == 1) {
+        if (threadIdx.x == 0) hooks.pending = atomicAdd(ticket, 1u);
+    }
     for (uint32_t it = 0;; ++it) {
         const uint32_t prime = fr / batch, poly = fr % batch;
         const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
         f.init_consts(consts[prime].q);
         hooks.slot = it & 1u;
-        if (threadIdx.x == 0) mailbox[it & 1u] = atomicAdd(ticket, 1u) + gridDim.x;   // read by everyone after this frame's barrier
+        if constexpr (PF == 1) {
+            if (threadIdx.x == 0) mailbox[it & 1u] = hooks.pending + gridDim.x;      // drawn during the previous frame's last pass
+        } else {
+            if (threadIdx.x == 0) mailbox[it & 1u] = atomicAdd(ticket, 1u) + gridDim.x;   // read by everyone after this frame's barrier
+        }
         uint64_t x[C];
         if constexpr (F::TRACE) {
             uint64_t t_top;
@@ -1211,7 +1239,7 @@ constexpr rb_entry make_entry2(int id) {
                     &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>, 0, nullptr, false};
 }
 
-template <int L, int R, int ARITH, int MINW>
+template <int L, int R, int ARITH, int MINW, int PF>
 hipError_t launch_rb2_stream_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     static int resident = 0;
@@ -1226,26 +1254,26 @@ hipError_t launch_rb2_stream_t(const plan_view& pv, const uint64_t* in, uint64_t
     if (total >= (1ull << 31) || !pv.ticket) return hipErrorInvalidValue;
     const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
     const unsigned grid = (unsigned)(total < (uint64_t)resident ? total : (uint64_t)resident);
-    hipLaunchKernelGGL((fwd_rb2_stream<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, out, pv.consts, pv.tw_rb,
+    hipLaunchKernelGGL((fwd_rb2_stream<L, R, ARITH, MINW, PF>), dim3(grid), dim3(G::T), lds, s, in, out, pv.consts, pv.tw_rb,
                        pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride,
                        (uint32_t)(fl.lazy_out ? 1 : 0), pv.ticket);
     return hipGetLastError();
 }
 
-template <int L, int R, int ARITH, int MINW>
+template <int L, int R, int ARITH, int MINW, int PF>
 hipError_t init_rb2_stream_t() {
     hipError_t e = init_rb2_t<L, R, 1, ARITH, MINW>();
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_stream<L, R, ARITH, MINW>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_stream<L, R, ARITH, MINW, PF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb2_lds_bytes<L, R, 1, ARITH>() + 16);
     return e;
 }
 
-template <int L, int R, int ARITH, int MINW>
+template <int L, int R, int ARITH, int MINW, int PF = 0>
 constexpr rb_entry make_entry_stream(int id) {
     rb_entry e = make_entry2<L, R, 1, ARITH, MINW>(id);
-    e.launch = &launch_rb2_stream_t<L, R, ARITH, MINW>;
-    e.init = &init_rb2_stream_t<L, R, ARITH, MINW>;
+    e.launch = &launch_rb2_stream_t<L, R, ARITH, MINW, PF>;
+    e.init = &init_rb2_stream_t<L, R, ARITH, MINW, PF>;
     return e;
 }
 
@@ -1363,6 +1391,7 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8>(50),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptTrace) << 1), 8>(70),   // diagnostics only: id 90 + stamps
     make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one stream per plan
+    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8, 1>(84),
     // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv) << 1), 8>(90),
