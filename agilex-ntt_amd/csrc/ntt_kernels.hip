@@ -1396,7 +1396,7 @@ const rb_entry kRbEntries[] = {
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv) << 1), 8>(90),
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(40),
