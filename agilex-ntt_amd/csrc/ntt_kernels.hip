@@ -1395,6 +1395,7 @@ const rb_entry kRbEntries[] = {
     // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv) << 1), 8>(90),
+    make_entry2<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 4>(66),   // A/B: R = 4 (three passes, 4-wave workgroups) at 4 waves/SIMD, within 1.5 % of id 90
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),

@@ -167,7 +167,7 @@ def test_structured_known_answers(agx, dev, n):
 
 
 @pytest.mark.parametrize("bits", [30, 60, 61, 62])
-@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 70, 83, 84, 90, 91, 92])
+@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 66, 70, 83, 84, 90, 91, 92])
 def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     """every registered n=4096 kernel (first-generation exact; second-generation exact, fast and
     16q-lazy; the priority-raising defaults 90/91/92, the trace twin 70, the streaming kernel 83) against the oracle, for 30-, 60-, 61- and 62-bit moduli; a form whose lazy range does
@@ -176,7 +176,7 @@ def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes, inverse=False)
     if config != "default":
         # fast forms need q <= 2^61, the 16q-lazy form q <= 2^60: anything else must be refused
-        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 70, 83, 84, 90) and bits >= 61)
+        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 70, 83, 84, 90) and bits >= 61)
         if illegal:
             with pytest.raises(agx.AgxError) as ei:
                 plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
