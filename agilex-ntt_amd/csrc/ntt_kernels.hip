@@ -364,6 +364,9 @@ constexpr int kOptPrioStore = 256;
 constexpr int kOptPrioBarrier = 512;   // with kOptPrio: stay at priority until the frame's one s_barrier has been passed
 constexpr int kOptLazyInv = 2048;      // with kOptLazy16: inverse butterflies keep sums up to 16q (26 instead of 48 conditional subtracts per thread at n=4096)
 constexpr int kOptTwAheadInv = 4096;   // inverse: the next per-lane pass's first-stage twiddles (entries 4..7) fetched during the current pass's last stage
+constexpr int kOptAblateTw = 8192;     // timing only (wrong results): every lane reads column 0 of the per-lane tables (L1-resident)
+constexpr int kOptAblateHbm = 16384;   // timing only (wrong results): every workgroup transforms frame 0 of its prime (L2-resident)
+constexpr int kOptAblateLdOnly = 32768, kOptAblateStOnly = 65536;   // with kOptAblateHbm: only the loads / only the stores go to the hot frame
 constexpr int kOptScalarBase = 1024;   // frame loads as (uniform pointer per register) + lane offset: no per-load VALU address arithmetic
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
@@ -478,7 +481,7 @@ struct rb2_frame {
             t.col = nullptr;
             t.hstride = 0;
         } else {
-            t.col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + high;
+            t.col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + ((OPT & kOptAblateTw) ? 0u : high);
             t.hstride = (uint32_t)H << split_log;
         }
     }
@@ -547,7 +550,7 @@ struct rb2_frame {
                 if constexpr (twa_next && S == (ns > 1 ? ns - 1 : 0)) {
                     // `ahead` is free once this pass's first two stages are done
                     constexpr int pn = p + 1;
-                    const twpair* ncol = tbl + G::table_off(pn) * (1u << split_log) + (size_t)blk * G::H(pn) + (tid >> G::rlo(pn));
+                    const twpair* ncol = tbl + G::table_off(pn) * (1u << split_log) + (size_t)blk * G::H(pn) + ((OPT & kOptAblateTw) ? 0u : (tid >> G::rlo(pn)));
                     const uint32_t nstride = (uint32_t)G::H(pn) << split_log;
                     static_for<1, C / 2>([&](auto J) { constexpr int j = J; ahead[j] = ncol[(size_t)j * nstride]; });
                 }
@@ -746,6 +749,15 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     AGX_RB2_PROLOGUE;
     f.lazy_out = lazy_out != 0;
     uint64_t x[C];
+    if constexpr (((ARITH >> 1) & kOptAblateHbm) != 0) {
+        const int64_t hot = (int64_t)prime * prime_stride;     // frame 0 of the prime, in and out
+        const uint64_t* src = in + ((((ARITH >> 1) & kOptAblateStOnly) != 0) ? base : hot);
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = (src + (uint32_t)r * T)[f.tid];
+        f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
+        f.store_last_layout(x, out, (((ARITH >> 1) & kOptAblateLdOnly) != 0) ? base : hot, live);
+        return;
+    }
     if constexpr (F::SCALAR_BASE) {
         const uint64_t* src = in + base;     // wave-uniform
 #pragma unroll
@@ -1396,6 +1408,15 @@ const rb_entry kRbEntries[] = {
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv) << 1), 8>(90),
     make_entry2<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 4>(66),   // A/B: R = 4 (three passes, 4-wave workgroups) at 4 waves/SIMD, within 1.5 % of id 90
+#ifdef AGX_TIMING_ABLATIONS
+    // timing only, WRONG RESULTS (make EXTRA=-DAGX_TIMING_ABLATIONS): the default kernel without per-lane twiddle
+    // traffic (67), with L2-resident frames (68: loads and stores, 71: loads only, 72: stores only), with neither (69)
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptAblateTw) << 1), 8>(67),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptAblateHbm) << 1), 8>(68),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptAblateTw | kOptAblateHbm) << 1), 8>(69),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptAblateHbm | kOptAblateLdOnly) << 1), 8>(71),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptAblateHbm | kOptAblateStOnly) << 1), 8>(72),
+#endif
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
