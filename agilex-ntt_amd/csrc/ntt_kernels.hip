@@ -367,6 +367,7 @@ constexpr int kOptTwAheadInv = 4096;   // inverse: the next per-lane pass's firs
 constexpr int kOptAblateTw = 8192;     // timing only (wrong results): every lane reads column 0 of the per-lane tables (L1-resident)
 constexpr int kOptAblateHbm = 16384;   // timing only (wrong results): every workgroup transforms frame 0 of its prime (L2-resident)
 constexpr int kOptAblateLdOnly = 32768, kOptAblateStOnly = 65536;   // with kOptAblateHbm: only the loads / only the stores go to the hot frame
+constexpr int kOptNtLoad = 131072, kOptNtStore = 262144;   // non-temporal frame loads / result stores (data touched once)
 constexpr int kOptScalarBase = 1024;   // frame loads as (uniform pointer per register) + lane offset: no per-load VALU address arithmetic
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
@@ -693,7 +694,11 @@ struct rb2_frame {
         if constexpr (PRIO_STORE) __builtin_amdgcn_s_setprio(3);
         if (live) {
             const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
-            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[base + e0 + 64u * (uint32_t)r] = slab[join(s0, img(64u * (uint32_t)r))]; });
+            static_for<0, C>([&](auto Rr) {
+                constexpr int r = Rr;
+                if constexpr ((OPT & kOptNtStore) != 0) __builtin_nontemporal_store(slab[join(s0, img(64u * (uint32_t)r))], &out[base + e0 + 64u * (uint32_t)r]);
+                else out[base + e0 + 64u * (uint32_t)r] = slab[join(s0, img(64u * (uint32_t)r))];
+            });
         }
     }
     // `in2` (may be null): the coefficient-wise product in * in2 mod q is taken while loading, so a
@@ -703,9 +708,9 @@ struct rb2_frame {
         const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            uint64_t v = in[base + e0 + 64u * (uint32_t)r];
+            uint64_t v = (OPT & kOptNtLoad) ? __builtin_nontemporal_load(&in[base + e0 + 64u * (uint32_t)r]) : in[base + e0 + 64u * (uint32_t)r];
             if (in2) {   // wave-uniform
-                const uint64_t u = in2[base + e0 + 64u * (uint32_t)r];
+                const uint64_t u = (OPT & kOptNtLoad) ? __builtin_nontemporal_load(&in2[base + e0 + 64u * (uint32_t)r]) : in2[base + e0 + 64u * (uint32_t)r];
                 v = mul_mod_barrett(reduce_4q(v, k.q, k.q << 1), reduce_4q(u, k.q, k.q << 1), bk);
             }
             if constexpr (!FAST) v = csub(v, k.m);    // exact form wants [0,2q); inputs may be < 4q
@@ -758,7 +763,11 @@ fwd_rb2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
         f.store_last_layout(x, out, (((ARITH >> 1) & kOptAblateLdOnly) != 0) ? base : hot, live);
         return;
     }
-    if constexpr (F::SCALAR_BASE) {
+    if constexpr (((ARITH >> 1) & kOptNtLoad) != 0) {
+        const uint64_t* src = in + base;     // wave-uniform
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = __builtin_nontemporal_load(src + (uint32_t)r * T + f.tid);
+    } else if constexpr (F::SCALAR_BASE) {
         const uint64_t* src = in + base;     // wave-uniform
 #pragma unroll
         for (int r = 0; r < C; ++r) x[r] = (src + (uint32_t)r * T)[f.tid];
@@ -981,8 +990,9 @@ fwd_rb2_pair(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     const twpair w1 = load_uniform(tw_nat + ((size_t)prime << (L + 1)) + 1);
 
     uint64_t lo[C], hi[C];
-    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; lo[r] = in[frame + f.tid + (uint32_t)r * T]; });
-    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; hi[r] = in[frame + (1 << L) + f.tid + (uint32_t)r * T]; });
+    constexpr bool NT = ((ARITH >> 1) & kOptNtLoad) != 0;
+    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; lo[r] = NT ? __builtin_nontemporal_load(&in[frame + f.tid + (uint32_t)r * T]) : in[frame + f.tid + (uint32_t)r * T]; });
+    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; hi[r] = NT ? __builtin_nontemporal_load(&in[frame + (1 << L) + f.tid + (uint32_t)r * T]) : in[frame + (1 << L) + f.tid + (uint32_t)r * T]; });
     static_for<0, C>([&](auto Rr) { constexpr int r = Rr; f.template butterfly<0>(lo[r], hi[r], w1); });
     f.blk = 0;
     f.forward(lo, tbl);
@@ -1008,7 +1018,10 @@ inv_rb2(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint6
     f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);
     if (live) {
 #pragma unroll
-        for (int r = 0; r < C; ++r) out[base + f.tid + (uint32_t)r * T] = x[r];
+        for (int r = 0; r < C; ++r) {
+            if constexpr (((ARITH >> 1) & kOptNtStore) != 0) __builtin_nontemporal_store(x[r], &out[base + f.tid + (uint32_t)r * T]);
+            else out[base + f.tid + (uint32_t)r * T] = x[r];
+        }
     }
 }
 
@@ -1049,8 +1062,17 @@ inv_rb2_pair(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, 
         lo[r] = reduce_final_inv<FAST, F::SEL>(lo[r], f.k, f.fc);
         hi[r] = reduce_final_inv<FAST, F::SEL>(hi[r], f.k, f.fc);
     });
-    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[frame + f.tid + (uint32_t)r * T] = lo[r]; });
-    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; out[frame + (1 << L) + f.tid + (uint32_t)r * T] = hi[r]; });
+    constexpr bool NTS = ((ARITH >> 1) & kOptNtStore) != 0;
+    static_for<0, C>([&](auto Rr) {
+        constexpr int r = Rr;
+        if constexpr (NTS) __builtin_nontemporal_store(lo[r], &out[frame + f.tid + (uint32_t)r * T]);
+        else out[frame + f.tid + (uint32_t)r * T] = lo[r];
+    });
+    static_for<0, C>([&](auto Rr) {
+        constexpr int r = Rr;
+        if constexpr (NTS) __builtin_nontemporal_store(hi[r], &out[frame + (1 << L) + f.tid + (uint32_t)r * T]);
+        else out[frame + (1 << L) + f.tid + (uint32_t)r * T] = hi[r];
+    });
 }
 
 // c = INTT(NTT(a) o NTT(b)) for one frame without leaving the chip: both forward transforms end in
@@ -1401,12 +1423,12 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(27),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(39),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8>(50),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptTrace) << 1), 8>(70),   // diagnostics only: id 90 + stamps
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptNtLoad | kOptNtStore | kOptTrace) << 1), 8>(70),   // diagnostics only: id 90 + stamps
     make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one stream per plan
     make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8, 1>(84),
     // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv) << 1), 8>(90),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore) << 1), 8>(90),
     make_entry2<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 4>(66),   // A/B: R = 4 (three passes, 4-wave workgroups) at 4 waves/SIMD, within 1.5 % of id 90
 #ifdef AGX_TIMING_ABLATIONS
     // timing only, WRONG RESULTS (make EXTRA=-DAGX_TIMING_ABLATIONS): the default kernel without per-lane twiddle
@@ -1422,30 +1444,30 @@ const rb_entry kRbEntries[] = {
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(40),
-    make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv) << 1), 8>(61),
+    make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(61),
     make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
     make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31),
-    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv) << 1), 8>(41),
+    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(41),
     make_entry2<13, 3, 1, 0 | (kOptPad << 1), 8>(34),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(33),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(42),
-    make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv) << 1), 8>(64),
+    make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(64),
     make_entry2_invpair<14, 4, 0 | (kOptPad << 1), 4>(36),
     make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect) << 1), 4>(35),
-    make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead) << 1), 4>(43),
+    make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 4>(43),
     // n = 16384 / 32768 as 2 / 4 resident blocks of 8192 (8 waves/SIMD) with fused leading stages
     make_entry_split<13, 3, 1, 0 | (kOptPad << 1), 8, 1>(44),
     make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8, 1>(45),
-    make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8, 1>(46),
+    make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptNtLoad | kOptNtStore) << 1), 8, 1>(46),
     make_entry_split<13, 3, 1, 0 | (kOptPad << 1), 8, 2>(47),
     make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8, 2>(48),
-    make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8, 2>(49),
+    make_entry_split<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptNtLoad | kOptNtStore) << 1), 8, 2>(49),
     // n = 16384: one workgroup per frame, its two 8192-halves in turn (in-place safe, no redundant work)
     make_entry_pair<13, 3, 0 | (kOptPad << 1), 8>(51),
     make_entry_pair<13, 3, 1 | ((kOptPad | kOptSelect) << 1), 8>(52),
-    make_entry_pair<13, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(53),
+    make_entry_pair<13, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptNtLoad | kOptNtStore) << 1), 8>(53),
     // n = 32768 the same way: 1024 threads hold the frame (32 coefficients each), two 16384-halves in turn
-    make_entry_pair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 4>(54),
+    make_entry_pair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptNtLoad | kOptNtStore) << 1), 4>(54),
     make_entry_pair<14, 4, 1 | ((kOptPad | kOptSelect) << 1), 4>(55),
     make_entry_pair<14, 4, 0 | (kOptPad << 1), 4>(56),
 };
