@@ -1091,12 +1091,13 @@ polymul_rb2(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint
     // both forward transforms may skip their last two conditional subtracts
     f.lazy_out = F::LAZY16;
     uint64_t xa[C], xb[C];
+    constexpr bool NTL = ((ARITH >> 1) & kOptNtLoad) != 0, NTS = ((ARITH >> 1) & kOptNtStore) != 0;
 #pragma unroll
-    for (int r = 0; r < C; ++r) xa[r] = a[base + f.tid + (uint32_t)r * T];
+    for (int r = 0; r < C; ++r) xa[r] = NTL ? __builtin_nontemporal_load(&a[base + f.tid + (uint32_t)r * T]) : a[base + f.tid + (uint32_t)r * T];
     f.forward(xa, tw_rb + (size_t)prime * pairs_per_prime);
     // b is fetched only now: holding it across NTT(a) would cost 2^R more register pairs and spill
 #pragma unroll
-    for (int r = 0; r < C; ++r) xb[r] = b[base + f.tid + (uint32_t)r * T];
+    for (int r = 0; r < C; ++r) xb[r] = NTL ? __builtin_nontemporal_load(&b[base + f.tid + (uint32_t)r * T]) : b[base + f.tid + (uint32_t)r * T];
     __syncthreads();   // the image is reused: every wave must be done reading NTT(a)'s exchanges
     f.forward(xb, tw_rb + (size_t)prime * pairs_per_prime);
 #pragma unroll
@@ -1104,7 +1105,10 @@ polymul_rb2(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint
     f.inverse(xa, itw_rb + (size_t)prime * pairs_per_prime, pc);
     if (live) {
 #pragma unroll
-        for (int r = 0; r < C; ++r) c[base + f.tid + (uint32_t)r * T] = xa[r];
+        for (int r = 0; r < C; ++r) {
+            if constexpr (NTS) __builtin_nontemporal_store(xa[r], &c[base + f.tid + (uint32_t)r * T]);
+            else c[base + f.tid + (uint32_t)r * T] = xa[r];
+        }
     }
 }
 
