@@ -394,6 +394,7 @@ struct rb2_frame {
     static constexpr bool PRIO = (OPT & kOptPrio) != 0, PRIO_STORE = (OPT & kOptPrioStore) != 0;
     static constexpr bool PRIO_BARRIER = PRIO && (OPT & kOptPrioBarrier) != 0, SCALAR_BASE = (OPT & kOptScalarBase) != 0;
     static constexpr bool LAZY_INV = LAZY16 && (OPT & kOptLazyInv) != 0;
+    static constexpr bool NT_LOAD = (OPT & kOptNtLoad) != 0;
     static constexpr bool TWA_INV = (OPT & kOptTwAheadInv) != 0 && R == 3;
     mutable uint64_t ts[12];
     uint64_t trace_wave = ~0ull;   // row of the trace buffer (default: launch-wide wave number)
@@ -814,7 +815,7 @@ struct rb2_stream_hooks {
             if (next < total) {     // wave-uniform
                 const int64_t nb = (int64_t)(next / batch) * prime_stride + (int64_t)(next % batch) * poly_stride;
 #pragma unroll
-                for (int r = 0; r < C; ++r) xn[r] = in[nb + f.tid + (uint32_t)r * T];
+                for (int r = 0; r < C; ++r) xn[r] = F::NT_LOAD ? __builtin_nontemporal_load(&in[nb + f.tid + (uint32_t)r * T]) : in[nb + f.tid + (uint32_t)r * T];
             }
         }
     }
@@ -826,8 +827,8 @@ struct rb2_stream_hooks {
             const uint32_t fn = next < total ? next : total - 1;
             const uint64_t* src = in + (int64_t)(fn / batch) * prime_stride + (int64_t)(fn % batch) * poly_stride;
             asm volatile("" ::: "memory");
-            xn[2 * b] = (src + (uint32_t)(2 * b) * T)[f.tid];
-            xn[2 * b + 1] = (src + (uint32_t)(2 * b + 1) * T)[f.tid];
+            xn[2 * b] = F::NT_LOAD ? __builtin_nontemporal_load(src + (uint32_t)(2 * b) * T + f.tid) : (src + (uint32_t)(2 * b) * T)[f.tid];
+            xn[2 * b + 1] = F::NT_LOAD ? __builtin_nontemporal_load(src + (uint32_t)(2 * b + 1) * T + f.tid) : (src + (uint32_t)(2 * b + 1) * T)[f.tid];
             asm volatile("" ::: "memory");
         }
     }
@@ -864,7 +865,7 @@ fwd_rb2_stream(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     {
         const int64_t b0 = (int64_t)(fr / batch) * prime_stride + (int64_t)(fr % batch) * poly_stride;
 #pragma unroll
-        for (int r = 0; r < C; ++r) xn[r] = in[b0 + f.tid + (uint32_t)r * T];
+        for (int r = 0; r < C; ++r) xn[r] = F::NT_LOAD ? __builtin_nontemporal_load(&in[b0 + f.tid + (uint32_t)r * T]) : in[b0 + f.tid + (uint32_t)r * T];
     }
     rb2_stream_hooks<F, PF> hooks{in, xn, f, mailbox, ticket, 0, total, batch, prime_stride, poly_stride, 0, 0};
     if constexpr (PF == 1) {
@@ -1428,8 +1429,8 @@ const rb_entry kRbEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(39),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8>(50),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptNtLoad | kOptNtStore | kOptTrace) << 1), 8>(70),   // diagnostics only: id 90 + stamps
-    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 6>(83),   // A/B only: one stream per plan
-    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead) << 1), 8, 1>(84),
+    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 6>(83),   // A/B only: one stream per plan
+    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 8, 1>(84),
     // wave priority raised from launch until the frame's one all-wave barrier has been passed: +2 % at n=4096
     // (90/92/91 are the defaults there), -2..-3 % at n=1024/2048/8192, nothing at 16384 (not registered)
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore) << 1), 8>(90),
