@@ -32,7 +32,6 @@ ABI = {
     "agx_ntt_strerror": (ctypes.c_char_p, [_int]),
     "agx_ntt_last_hip_error": (_int, []),
     "agx_ntt_device_count": (_int, [ctypes.POINTER(_int)]),
-    "agx_ntt_debug_set_trace_buffer": (_int, [_vp, _u64]),
     "agx_ntt_forward_host": (_int, [_p64, _p64, _p64, _p64, _p64, _p64, _u32, _u32]),
     "agx_ntt_forward_host_stream": (_int, [_vp, _p64, _p64, _p64, _u64]),
     "agx_ntt_plan_create": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64, _p64, _p64, _p64]),
@@ -65,7 +64,7 @@ class AgxError(RuntimeError):
 
 def build(verbose=False):
     """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", _HERE, "build"]
+    cmd = ["make", "-C", _HERE, f"-j{min(8, os.cpu_count() or 1)}", "build"]
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
@@ -119,9 +118,39 @@ def _np_ptr(a):
     return a.ctypes.data_as(_p64)
 
 
+def kernel_source_sha16():
+    """sha256[:16] over the device/host sources the library is built from (csrc/, sorted by name): ties a
+    committed PMC figure (profiles/hbm_traffic.json) to the build it was measured on"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "**", "*"), recursive=True)):
+        if os.path.isfile(f) and f.rsplit(".", 1)[-1] in ("hip", "hpp", "cpp", "h", "s", "py"):
+            h.update(os.path.relpath(f, _HERE).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libagxntt_diag.so")   # `make diag`: product + diagnostics kernels (tools/agx_ntt_diag.h)
+
+
+def build_diag():
+    """Compile lib/libagxntt_diag.so (trace twin, streaming A/B kernels); load it with AGX_NTT_LIB=DIAG_LIB_PATH."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, f"-j{min(8, os.cpu_count() or 1)}", "diag"])
+    return DIAG_LIB_PATH
+
+
 def debug_set_trace_buffer(d_buf, nbytes):
-    """Diagnostics (tools/timeline.py): where the registry's trace kernel writes its phase stamps; (0, 0) = off."""
-    _check(lib().agx_ntt_debug_set_trace_buffer(d_buf, nbytes), "debug_set_trace_buffer")
+    """Diagnostics (tools/timeline.py), diag library only: where the registry's trace kernel writes its phase
+    stamps; (0, 0) = off.  The product library does not export the hook."""
+    try:
+        fn = lib().agx_ntt_debug_set_trace_buffer
+    except AttributeError:
+        raise RuntimeError("agx_ntt_debug_set_trace_buffer is only in lib/libagxntt_diag.so: `make -C agilex-ntt_amd diag` "
+                           "and run with AGX_NTT_LIB=<that file>") from None
+    fn.restype, fn.argtypes = _int, [_vp, _u64]
+    _check(fn(d_buf, nbytes), "debug_set_trace_buffer")
 
 
 def device_count():

@@ -7,11 +7,15 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "host_math.hpp"
 #include "ntt_kernels.hpp"
+#ifdef AGX_DIAG
+namespace agx { hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves); }
+#endif
 
 using namespace agx;
 
@@ -49,6 +53,17 @@ int hip_fail(hipError_t e) {
         hipError_t e_ = (expr);                          \
         if (e_ != hipSuccess) return hip_fail(e_);       \
     } while (0)
+
+// function attributes (large dynamic LDS) are per device and never change: set them once per device,
+// not on every plan creation
+hipError_t kernels_init_once(int device) {
+    constexpr int kMaxDevices = 64;
+    static std::once_flag once[kMaxDevices];
+    static hipError_t result[kMaxDevices];
+    if (device < 0 || device >= kMaxDevices) return kernels_init();
+    std::call_once(once[device], [device] { result[device] = kernels_init(); });
+    return result[device];
+}
 
 int check_size(uint32_t n) {
     return (n >= AGX_NTT_MIN_N && n <= AGX_NTT_MAX_N && is_pow2(n)) ? AGX_OK : AGX_ERR_BAD_SIZE;
@@ -119,7 +134,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     if (psi) p->psi.assign(psi, psi + num_primes);
     int rc = AGX_OK;
     hipError_t he = hipGetDevice(&p->device);
-    if (he == hipSuccess) he = kernels_init();
+    if (he == hipSuccess) he = kernels_init_once(p->device);
     if (he != hipSuccess) { free_plan(p); return hip_fail(he); }
 
     std::vector<prime_consts> consts(num_primes);
@@ -137,6 +152,11 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         for (uint32_t j = 1; j < n && p->arith_level > 0; ++j) {
             const uint64_t w = tw[(size_t)k * n + j];
             if (w >= q || pre[(size_t)k * n + j] != shoup_quotient(w, q)) p->arith_level = 0;
+            // the inverse kernels of a plan use the same arithmetic form: its tables must honour the contract too
+            if (itw && p->arith_level > 0) {
+                const uint64_t iw = itw[(size_t)k * n + j];
+                if (iw >= q || ipre[(size_t)k * n + j] != shoup_quotient(iw, q)) p->arith_level = 0;
+            }
         }
     }
     p->rb = regblock_choose(n, -1, p->arith_level);
@@ -186,6 +206,8 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
 
 int check_call(const agx_ntt_plan* plan, const void* a, const void* b, uint64_t batch, int64_t prime_stride, int64_t poly_stride) {
     if (!plan || !a || !b) return AGX_ERR_NULL_POINTER;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != plan->device) return AGX_ERR_BAD_ARGUMENT;   // the plan's tables live on plan->device
     if (prime_stride < 0 || poly_stride < 0) return AGX_ERR_BAD_ARGUMENT;
     if (batch > 1 && poly_stride < (int64_t)plan->n) return AGX_ERR_BAD_ARGUMENT;   // frames would overlap
     if ((batch << (plan->log_n > 14 ? plan->log_n - 14 : 0)) > 0x7fffffffull) return AGX_ERR_BAD_ARGUMENT;  // grid.x limit
@@ -227,11 +249,14 @@ int agx_ntt_device_count(int* count) {
     return AGX_OK;
 }
 
+#ifdef AGX_DIAG
+// lib/libagxntt_diag.so only (tools/agx_ntt_diag.h): where the registry's trace kernel writes its phase stamps
 int agx_ntt_debug_set_trace_buffer(void* d_buf, uint64_t bytes) {
     if (!d_buf && bytes) return AGX_ERR_NULL_POINTER;
     AGX_HIP(agx::regblock_set_trace(static_cast<uint64_t*>(d_buf), bytes / 128));
     return AGX_OK;
 }
+#endif
 
 int agx_ntt_plan_create(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, const uint64_t* moduli,
                         const uint64_t* twiddles, const uint64_t* precons,
@@ -403,6 +428,8 @@ int agx_ntt_inverse(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_
 
 int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c, uint64_t batch, void* stream) {
     if (!plan || !d_a || !d_b || !d_c) return AGX_ERR_NULL_POINTER;
+    int rc = check_call(plan, d_a, d_c, batch, (int64_t)(batch * plan->n), (int64_t)plan->n);
+    if (rc) return rc;
     if (batch == 0) return AGX_OK;
     AGX_HIP(launch_pointwise(view_of(plan), d_a, d_b, d_c, batch, static_cast<hipStream_t>(stream)));
     return AGX_OK;
@@ -411,6 +438,8 @@ int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint6
 int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                     uint64_t* d_scratch, uint64_t batch, void* stream) {
     if (!plan || !d_a || !d_b || !d_c) return AGX_ERR_NULL_POINTER;
+    int rc = check_call(plan, d_a, d_c, batch, (int64_t)(batch * plan->n), (int64_t)plan->n);
+    if (rc) return rc;
     if (!plan->has_inverse) return AGX_ERR_NO_INVERSE;
     if (batch == 0) return AGX_OK;
     if (use_regblock(plan) && regblock_has_polymul(plan->rb) && plan->d_itw_rb) {
@@ -422,7 +451,6 @@ int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_
     }
     if (!d_scratch) return AGX_ERR_NULL_POINTER;
     if (d_scratch == d_a || d_scratch == d_b || d_scratch == d_c) return AGX_ERR_BAD_ARGUMENT;
-    int rc;
     // scratch <- NTT(a); c <- NTT(b) (a is dead by now, so c may alias it); c <- INTT(c o scratch).
     // With the register-blocked inverse the product is taken while it loads (no pointwise pass) and
     // the forward results may stay lazily reduced.
@@ -442,6 +470,8 @@ int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_
 
 int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t batch, uint64_t first_poly, uint64_t seed, void* stream) {
     if (!plan || !d_out) return AGX_ERR_NULL_POINTER;
+    int rc = check_call(plan, d_out, d_out, batch, (int64_t)(batch * plan->n), (int64_t)plan->n);
+    if (rc) return rc;
     if (batch == 0) return AGX_OK;
     AGX_HIP(launch_fill(view_of(plan), d_out, batch, first_poly, seed, static_cast<hipStream_t>(stream)));
     return AGX_OK;
@@ -529,6 +559,20 @@ int agx_ntt_forward_host_stream(const agx_ntt_plan* plan, const uint64_t* in, co
     return e == hipSuccess ? AGX_OK : hip_fail(e);
 }
 
+// One-shot calls usually repeat with the same (n, modulus, tables): building a plan verifies every table
+// entry (a 128-bit divide each) and uploads four tables, which costs tens of milliseconds, so the last
+// plan is kept and reused while the caller's tables still compare equal word for word.
+namespace {
+struct oneshot_cache {
+    std::mutex mu;
+    agx_ntt_plan* plan = nullptr;
+    int device = -1;
+    uint64_t q = 0;
+    std::vector<uint64_t> tw, pre;     // host copies of the tables the cached plan was built from
+};
+oneshot_cache g_oneshot;
+}  // namespace
+
 int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
                          const uint64_t* twiddles, const uint64_t* precons, uint64_t* out,
                          uint32_t n, uint32_t num_frames) {
@@ -537,11 +581,23 @@ int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t
     if (rc) return rc;
     if ((rc = check_modulus(modulus[0], n))) return rc;
     if (num_frames == 0) return AGX_OK;
-    agx_ntt_plan* plan = nullptr;
-    if ((rc = build_plan(&plan, n, 1, modulus, nullptr, twiddles, precons, nullptr, nullptr))) return rc;
-    rc = agx_ntt_forward_host_stream(plan, in, in2, out, num_frames);
-    free_plan(plan);
-    return rc;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return AGX_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lock(g_oneshot.mu);    // one-shot calls are synchronous; they also serialise
+    oneshot_cache& c = g_oneshot;
+    const bool hit = c.plan && c.device == dev && c.plan->n == n && c.q == modulus[0] &&
+                     std::memcmp(c.tw.data(), twiddles, (size_t)n * 8) == 0 && std::memcmp(c.pre.data(), precons, (size_t)n * 8) == 0;
+    if (!hit) {
+        agx_ntt_plan* plan = nullptr;
+        if ((rc = build_plan(&plan, n, 1, modulus, nullptr, twiddles, precons, nullptr, nullptr))) return rc;
+        if (c.plan && c.device == dev) free_plan(c.plan);   // (a plan of another device is left to that device's teardown)
+        c.plan = plan;
+        c.device = dev;
+        c.q = modulus[0];
+        c.tw.assign(twiddles, twiddles + n);
+        c.pre.assign(precons, precons + n);
+    }
+    return agx_ntt_forward_host_stream(c.plan, in, in2, out, num_frames);
 }
 
 int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t* primes_out) {

@@ -58,7 +58,6 @@ hipError_t launch_forward_radix2(const plan_view& pv, const uint64_t* in, uint64
 hipError_t launch_inverse_radix2(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
 hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s);
 bool regblock_has_inverse(const regblock_layout& rb);
-hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves);   // diagnostics: where the kOptTrace kernels write
 bool regblock_has_polymul(const regblock_layout& rb);   // fused NTT -> pointwise -> INTT in one kernel
 // in2 != null: transforms the coefficient-wise product in * in2 (the pointwise step fused into the load)
 hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s);

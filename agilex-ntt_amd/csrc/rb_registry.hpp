@@ -1,0 +1,52 @@
+// rb_registry.hpp -- the registry of register-blocked kernel configurations, shared by the translation
+// units that instantiate the kernels (reg_*.hip) and the one that looks entries up (ntt_kernels.hip).
+#pragma once
+#include "ntt_kernels.hpp"
+
+namespace agx {
+
+static constexpr int kMaxLdsLog = 14;  // 16384 coefficients = 128 KiB of the CU's 160 KiB LDS
+
+// ---- registry of register-blocked configurations -------------------------------------
+// id 0..: first entry for a given log_local is the tuned default; the others are kept for
+// A/B measurements (agx_ntt_plan_set_variant(plan, AGX_VARIANT_REGBLOCK_BASE + id)).
+struct rb_entry {
+    int id, log_local, r, ppb;
+    bool stage_out;
+    int min_waves;
+    uint32_t table_pairs;   // per sub-block
+    size_t lds_bytes;
+    void (*build)(const regblock_layout&, const uint64_t*, const uint64_t*, std::vector<ulonglong2>&);
+    hipError_t (*launch)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    hipError_t (*init)();
+    int arith;   // 0: exact (reference op sequence, q < 2^62); 1: fast (q <= 2^61); 2: 16q-lazy (q <= 2^60)
+    hipError_t (*launch_inv)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    hipError_t (*launch_mul)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    int fused_split;   // S > 0: `launch` is only for out != in and computes the S leading stages itself (n = 2^(log_local+S))
+    hipError_t (*launch_fused)(const plan_view&, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    bool fused_in_place_ok;   // launch_fused loads a whole frame before it stores any of it
+    // n = 2^(log_local+1): whole inverse (both resident halves + the last stage) in one launch, or null
+    hipError_t (*launch_inv_pair)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+};
+
+struct rb_span {
+    const rb_entry* first;
+    size_t count;
+};
+
+// one group per translation unit, so the ~50 kernel instantiations compile in parallel
+rb_span rb_entries_gen1();
+rb_span rb_entries_n1024();
+rb_span rb_entries_n2048();
+rb_span rb_entries_n4096();
+rb_span rb_entries_n4096_ab();
+rb_span rb_entries_n8192();
+rb_span rb_entries_n8192_split();
+rb_span rb_entries_n8192_pair();
+rb_span rb_entries_n16384();
+#ifdef AGX_DIAG
+rb_span rb_entries_diag();                                      // trace twin, streaming A/B kernels, timing ablations
+hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves);   // where the trace kernels write
+#endif
+
+}  // namespace agx

@@ -1,0 +1,18 @@
+// reg_n2048.hip -- one group of the kernel registry (rb_registry.hpp); ids are stable handles for tests
+// and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices.
+#define AGX_TU tu_n2048
+#include "rb_kernels.hpp"
+
+namespace agx {
+namespace AGX_TU {
+// n = 2048: two frames per 512-thread workgroup
+const rb_entry kEntries[] = {
+    make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
+    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31),
+    make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(41),
+};
+}  // namespace AGX_TU
+
+rb_span rb_entries_n2048() { return rb_span{AGX_TU::kEntries, sizeof(AGX_TU::kEntries) / sizeof(AGX_TU::kEntries[0])}; }
+
+}  // namespace agx

@@ -1,0 +1,20 @@
+// reg_n4096.hip -- one group of the kernel registry (rb_registry.hpp); ids are stable handles for tests
+// and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices.
+#define AGX_TU tu_n4096
+#include "rb_kernels.hpp"
+
+namespace agx {
+namespace AGX_TU {
+// n = 4096 defaults: wave priority raised from launch until the frame's one all-wave barrier has been passed (+2 %);
+// 90 = 16q-lazy (q <= 2^60), 92 = fast (q <= 2^61), 91 = exact (q < 2^62); 66 = R = 4 in three passes at 4 waves/SIMD (A/B, within 1.5 % of 90)
+const rb_entry kEntries[] = {
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore) << 1), 8>(90),
+    make_entry2<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 4>(66),   // A/B: R = 4 (three passes, 4-wave workgroups) at 4 waves/SIMD, within 1.5 % of id 90
+    make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
+};
+}  // namespace AGX_TU
+
+rb_span rb_entries_n4096() { return rb_span{AGX_TU::kEntries, sizeof(AGX_TU::kEntries) / sizeof(AGX_TU::kEntries[0])}; }
+
+}  // namespace agx

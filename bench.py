@@ -78,6 +78,85 @@ def cpu_baseline(target_seconds=12.0):
     }
 
 
+def _timed(torch, fn, launches, warmup):
+    """average duration (ms) of `launches` back-to-back calls of fn(i) after `warmup` untimed ones,
+    measured with events on the launch stream"""
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(launches):
+        fn(warmup + i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / launches
+
+
+def secondary_lines(torch, agx, plan4096, slabs, batch, stream):
+    """The other north_star paths on the same clock, same process, after the headline:
+    n=4096 inverse, n=4096 fused poly-mul, BASELINE configs[3] per-GPU slice (n=16384, 8 primes, batch 8192,
+    in place) and configs[4] per-GPU slice (n=32768 poly-mul, batch 1024).  Each entry: units/s, average
+    launch time (HIP events), algorithmic bytes per launch and the fraction of the 8 TB/s HBM roofline."""
+    out = []
+
+    def entry(name, workload, units, bytes_per_unit, ms, unit, launches, note=None):
+        gbs = units * bytes_per_unit / (ms * 1e-3) / 1e9
+        e = {"name": name, "workload": workload, "value": units / (ms * 1e-3), "unit": unit, "kernel_ms": ms,
+             "launches_timed": launches, "algorithmic_bytes_per_launch": units * bytes_per_unit,
+             "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+        if note:
+            e["note"] = note
+        out.append(e)
+
+    ns = len(slabs)
+    units = NUM_PRIMES * batch
+    # (1) n=4096 inverse, same slabs, in place (values are whatever the forward steps left: any input below 4q is legal)
+    ms = _timed(torch, lambda i: plan4096.inverse(slabs[i % ns].data_ptr(), slabs[i % ns].data_ptr(), batch, stream), 40, 8)
+    entry("inverse_n4096", f"n={N_COEFF}, {NUM_PRIMES} primes, batch {batch}, inverse NTT in place", units, 16 * N_COEFF, ms, "NTT/s", 40)
+    # (2) n=4096 fused polynomial product c = INTT(NTT(a) o NTT(b)), c aliasing a
+    ms = _timed(torch, lambda i: plan4096.polymul(slabs[i % ns].data_ptr(), slabs[(i + 1) % ns].data_ptr(), slabs[i % ns].data_ptr(), 0, batch, stream), 20, 4)
+    entry("polymul_n4096", f"n={N_COEFF}, {NUM_PRIMES} primes, batch {batch}, fused NTT x2 -> pointwise -> INTT in one launch (24n bytes per product)",
+          units, 24 * N_COEFF, ms, "products/s", 20,
+          note="three transforms per 24n bytes: bounded by VALU integer multiply issue, not HBM (DESIGN.md section 4)")
+    for s in slabs:
+        s.untyped_storage().resize_(0)      # give the 2 GiB back before the large slices
+    torch.cuda.empty_cache()
+
+    # (3) BASELINE configs[3] per-GPU slice: n=16384, 8 primes, batch 65536/8 = 8192 -> 65,536 NTTs, 8 GiB in place
+    n3, p3, b3 = 16384, 8, 8192
+    plan3 = agx.Plan(n3, agx.find_primes(PRIME_BITS, n3, p3))
+    buf = torch.empty(p3 * b3 * n3, dtype=torch.int64, device="cuda")
+    plan3.fill_synthetic(buf.data_ptr(), b3, 0, 42, stream)
+    ms = _timed(torch, lambda i: plan3.forward(buf.data_ptr(), buf.data_ptr(), b3, stream), 10, 2)
+    entry("forward_n16384_config4_slice", f"n={n3}, {p3} primes, batch {b3} per GPU (BASELINE.json configs[3] / 8 GPUs), forward in place, 8 GiB",
+          p3 * b3, 16 * n3, ms, "NTT/s", 10)
+    ms = _timed(torch, lambda i: plan3.inverse(buf.data_ptr(), buf.data_ptr(), b3, stream), 10, 2)
+    entry("inverse_n16384_config4_slice", f"n={n3}, {p3} primes, batch {b3} per GPU, inverse in place, 8 GiB", p3 * b3, 16 * n3, ms, "NTT/s", 10)
+    plan3.close()
+    del buf
+    torch.cuda.empty_cache()
+
+    # (4) BASELINE configs[4] per-GPU slice: n=32768 poly-mul, one 60-bit prime, batch 8192/8 = 1024;
+    # three (a, b) operand sets rotate (3 x 512 MiB) so the 256 MiB Infinity Cache cannot hold them
+    n4, b4, sets = 32768, 1024, 3
+    plan4 = agx.Plan(n4, agx.find_primes(PRIME_BITS, n4, 1))
+    ab = [[torch.empty(b4 * n4, dtype=torch.int64, device="cuda") for _ in range(2)] for _ in range(sets)]
+    for k, (a, b) in enumerate(ab):
+        plan4.fill_synthetic(a.data_ptr(), b4, 2 * k * b4, 42, stream)
+        plan4.fill_synthetic(b.data_ptr(), b4, (2 * k + 1) * b4, 42, stream)
+    c = torch.empty(b4 * n4, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(b4 * n4, dtype=torch.int64, device="cuda")
+    ms = _timed(torch, lambda i: plan4.polymul(ab[i % sets][0].data_ptr(), ab[i % sets][1].data_ptr(), c.data_ptr(), scratch.data_ptr(), b4, stream), 12, 3)
+    entry("polymul_n32768_config5_slice", f"n={n4}, one {PRIME_BITS}-bit prime, batch {b4} per GPU (BASELINE.json configs[4] / 8 GPUs), "
+          "c = INTT(NTT(a) o NTT(b)), operands never modified", b4, 24 * n4, ms, "products/s", 12,
+          note="VALU-bound like polymul_n4096")
+    ms = _timed(torch, lambda i: plan4.forward(ab[i % sets][0].data_ptr(), c.data_ptr(), b4, stream), 12, 3)
+    entry("forward_n32768", f"n={n4}, one prime, batch {b4}, forward out of place", b4, 16 * n4, ms, "NTT/s", 12)
+    plan4.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +166,7 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=RAMP_SECONDS,
                     help="set-up: run the step this long before the W warm-up steps so the GPU clock has ramped (0 = cold start)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (inverse, poly-mul, n=16384, n=32768)")
     args = ap.parse_args()
 
     import torch
@@ -162,11 +242,19 @@ def main():
     ntts_per_step_per_gpu = NUM_PRIMES * batch
     value = agx.aggregate_throughput(ntts_per_step_per_gpu, args.steps, world, elapsed)
     achieved = ntts_per_step_per_gpu * ALGO_BYTES_PER_NTT / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the PMC passes of tools/profile.sh (FETCH_SIZE x2 + WRITE_SIZE, separate runs,
+    # MI355X_MICROARCH.md): a figure of the build it was profiled on, so it is only reported while the kernel
+    # sources still hash to what that profile recorded; otherwise null (re-run tools/profile.sh)
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("bytes_per_launch")
+            tj = json.load(open(tfile))
+            if tj.get("kernel_source_sha16") == agx.kernel_source_sha16():
+                traffic = tj.get("bytes_per_launch")
+                traffic_source = {"profile": tj.get("tag"), "kernel_source_sha16": tj.get("kernel_source_sha16")}
+            else:
+                traffic_source = {"profile": tj.get("tag"), "stale": True}
         except Exception:
             traffic = None
     out = {
@@ -183,10 +271,12 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel_ms": kernel_ms,
+            "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": ntts_per_step_per_gpu * ALGO_BYTES_PER_NTT,
         },
     }
+    if world == 1 and not args.no_secondary:
+        out["secondary"] = secondary_lines(torch, agx, plan, slabs, batch, stream)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

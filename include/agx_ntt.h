@@ -53,10 +53,6 @@ typedef enum agx_status {
 const char* agx_ntt_strerror(int status);
 int agx_ntt_last_hip_error(void);     /* hipError_t of the last AGX_ERR_HIP on this thread */
 int agx_ntt_device_count(int* count); /* AGX_OK and *count = 0 when there is no GPU */
-/* Diagnostics for tools/timeline.py: the registry's trace kernel (AGX_VARIANT_REGBLOCK_BASE + 70) writes
- * 16 u64 per wave (12 s_memtime phase stamps, HW_ID, XCC_ID) into this device buffer; NULL/0 turns it off.
- * No reference counterpart. */
-int agx_ntt_debug_set_trace_buffer(void* d_buf, uint64_t bytes);
 
 /* ------------------------------------------------------------------------- */
 /* (1) One-shot host-pointer forward NTT.                                     */
@@ -77,7 +73,8 @@ int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t
 /* The same path for repeated calls and large inputs: tables stay on the device in `plan` (one modulus) */
 /* and host frames stream through pinned staging buffers with upload, transform and download          */
 /* overlapped on three HIP streams (the reference streams frames through its input/output kernels,    */
-/* src/kernel/ntt.cpp:508-640).  agx_ntt_forward_host is this call on a temporary plan.                */
+/* src/kernel/ntt.cpp:508-640).  agx_ntt_forward_host is this call on a plan it builds from the caller's */
+/* tables and keeps for the next call with the same (n, modulus, tables).                              */
 struct agx_ntt_plan;
 int agx_ntt_forward_host_stream(const struct agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2,
                                 uint64_t* out, uint64_t num_frames);
@@ -85,7 +82,8 @@ int agx_ntt_forward_host_stream(const struct agx_ntt_plan* plan, const uint64_t*
 /* ------------------------------------------------------------------------- */
 /* (2) Plans: device-resident tables for num_primes moduli of one size n.      */
 /* A plan is immutable after creation and may be shared between host threads;  */
-/* it belongs to the HIP device that was current when it was created.          */
+/* it belongs to the HIP device that was current when it was created: calls    */
+/* that take it return AGX_ERR_BAD_ARGUMENT while another device is current.   */
 /* ------------------------------------------------------------------------- */
 typedef struct agx_ntt_plan agx_ntt_plan;
 
@@ -127,8 +125,9 @@ int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint
 int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                       uint64_t batch, void* stream);
 /* c = a * b in Z_q[X]/(X^n + 1) = INTT(NTT(a) o NTT(b)); dense layout; c may alias a or b.
- * d_scratch: num_primes*batch*n elements of device memory owned by the caller, distinct from a, b, c;
- * only used (and may be NULL) when n has no fused kernel: today that is n < 1024 and n = 32768. */
+ * d_scratch: num_primes*batch*n elements of device memory owned by the caller, distinct from a, b, c.
+ * It is only used when n has no one-launch fused kernel -- today n < 1024 and n >= 16384 -- and may be NULL
+ * otherwise (1024 <= n <= 8192); a NULL scratch where one is needed returns AGX_ERR_NULL_POINTER. */
 int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                     uint64_t* d_scratch, uint64_t batch, void* stream);
 

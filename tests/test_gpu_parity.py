@@ -167,16 +167,17 @@ def test_structured_known_answers(agx, dev, n):
 
 
 @pytest.mark.parametrize("bits", [30, 60, 61, 62])
-@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 66, 70, 83, 84, 90, 91, 92])
+@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 66, 90, 91, 92])
 def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     """every registered n=4096 kernel (first-generation exact; second-generation exact, fast and
-    16q-lazy; the priority-raising defaults 90/91/92, the trace twin 70, the streaming kernel 83) against the oracle, for 30-, 60-, 61- and 62-bit moduli; a form whose lazy range does
+    16q-lazy; the priority-raising defaults 90/91/92) against the oracle, for 30-, 60-, 61- and 62-bit moduli (the diagnostics kernels 70/83/84
+    live in lib/libagxntt_diag.so: tests/test_gpu_diag.py); a form whose lazy range does
     not fit the modulus must be refused, and the default must fall back to a legal one"""
     n, batch, primes = 4096, 3, 2
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes, inverse=False)
     if config != "default":
         # fast forms need q <= 2^61, the 16q-lazy form q <= 2^60: anything else must be refused
-        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 70, 83, 84, 90) and bits >= 61)
+        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 90) and bits >= 61)
         if illegal:
             with pytest.raises(agx.AgxError) as ei:
                 plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
@@ -189,25 +190,6 @@ def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     d = dev.to_device(x)
     plan.forward(d.data_ptr(), d.data_ptr(), batch, dev.stream)
     assert np.array_equal(dev.to_host(d), _oracle_forward_rns(orc, x, tabs, n, batch))
-    plan.close()
-
-
-@pytest.mark.parametrize("config", [83, 84])
-def test_streaming_kernel_many_frames(agx, orc, dev, config):
-    """the streaming kernels (registry ids 83 / 84: resident workgroups drawing frames from a ticket counter,
-    next frame prefetched at the start of / staged through the last pass) on
-    more frames than workgroups, twice in a row (the counter resets itself), in place and strided by
-    prime, against the oracle"""
-    n, batch, primes = 4096, 1100, 2
-    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes, inverse=False)
-    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
-    rng = np.random.default_rng(config)
-    x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
-    want = _oracle_forward_rns(orc, x, tabs, n, batch)
-    for _ in range(2):
-        d = dev.to_device(x)
-        plan.forward(d.data_ptr(), d.data_ptr(), batch, dev.stream)
-        assert np.array_equal(dev.to_host(d), want)
     plan.close()
 
 
@@ -611,6 +593,117 @@ def test_config5_polymul_32768(agx, orc, dev):
     plan.close()
 
 
+def _oracle_polymul(orc, a, b, q, psi, n):
+    """INTT(NTT(a) o NTT(b)) through the oracle's own transforms, frame by frame"""
+    tw, pre = orc.make_tables(q, psi, n)
+    itw, _ = orc.make_inv_tables(q, psi, n)
+    fa = orc.forward(a % np.uint64(q), q, tw, pre, n)
+    fb = orc.forward(b % np.uint64(q), q, tw, pre, n)
+    return orc.inverse(orc.pointwise(fa, fb, q), q, itw, n)
+
+
+@pytest.mark.parametrize("bits", [60, 61, 62])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
+def test_polymul_every_fused_kernel(agx, orc, dev, n, bits):
+    """agx_ntt_polymul at every size with a fused path, in the 16q-lazy (60-bit), fast (61-bit) and exact (62-bit)
+    arithmetic: the one-launch polymul_rb2 kernels for n <= 8192 (registry defaults 61/41/90/64 and their fast /
+    exact siblings) and, at n = 16384, two lazy forward launches + the inverse kernel that multiplies while it
+    loads (in2 != NULL).  Expected: schoolbook product for n <= 2048, the oracle's NTT pipeline above that;
+    c distinct, c aliasing a, c aliasing b."""
+    batch, primes = 3, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
+    rng = np.random.default_rng(n * 7 + bits)
+    a = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+    b = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+    want = np.empty_like(a)
+    for p, t in enumerate(tabs):
+        for f in range(batch):
+            sl = slice((p * batch + f) * n, (p * batch + f + 1) * n)
+            want[sl] = orc.schoolbook(a[sl], b[sl], t[0], n) if n <= 2048 else _oracle_polymul(orc, a[sl], b[sl], t[0], t[1], n)
+    d_a, d_b, d_c, d_s = dev.to_device(a), dev.to_device(b), dev.empty(a.size), dev.empty(a.size)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_c), want)
+    assert np.array_equal(dev.to_host(d_a), a) and np.array_equal(dev.to_host(d_b), b)      # operands untouched
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_a.data_ptr(), d_s.data_ptr(), batch, dev.stream)   # c aliasing a
+    assert np.array_equal(dev.to_host(d_a), want)
+    d_a = dev.to_device(a)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_b.data_ptr(), d_s.data_ptr(), batch, dev.stream)   # c aliasing b
+    assert np.array_equal(dev.to_host(d_b), want)
+    plan.close()
+
+
+def test_polymul_lazy_operands(agx, orc, dev):
+    """operands anywhere in [0,4q) (the transforms' input contract) through the fused product at n=4096, 60-bit q:
+    the 16q-lazy forward results feed the Barrett product unreduced"""
+    n, batch = 4096, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, 1)
+    q, psi = tabs[0][0], tabs[0][1]
+    rng = np.random.default_rng(4242)
+    a = rand_coeffs(rng, batch * n, q, hi_mult=4)
+    b = np.concatenate([np.full(n, 4 * q - 1, dtype=np.uint64), rand_coeffs(rng, n, q, hi_mult=4)])
+    want = np.concatenate([_oracle_polymul(orc, a[f * n:(f + 1) * n], b[f * n:(f + 1) * n], q, psi, n) for f in range(batch)])
+    d_a, d_b, d_c = dev.to_device(a), dev.to_device(b), dev.empty(a.size)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_c), want)
+    plan.close()
+
+
+# every entry of the kernel registry with the size it serves and the largest modulus its arithmetic admits
+# (exact: 62 bits, fast: 61, 16q-lazy: 60); defaults are reached by the other tests, this one reaches the rest
+REGISTRY = [
+    (2, 4096, 62), (12, 4096, 61), (13, 4096, 62), (27, 4096, 61), (28, 4096, 62), (39, 4096, 60), (50, 4096, 60),
+    (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61),
+    (29, 1024, 61), (30, 1024, 62), (40, 1024, 60), (61, 1024, 60),
+    (31, 2048, 61), (32, 2048, 62), (41, 2048, 60),
+    (33, 8192, 61), (34, 8192, 62), (42, 8192, 60), (64, 8192, 60),
+    (35, 16384, 61), (36, 16384, 62), (43, 16384, 60),
+    (44, 16384, 62), (45, 16384, 61), (46, 16384, 60), (47, 32768, 62), (48, 32768, 61), (49, 32768, 60),
+    (51, 16384, 62), (52, 16384, 61), (53, 16384, 60), (54, 32768, 60), (55, 32768, 61), (56, 32768, 62),
+]
+
+
+@pytest.mark.parametrize("config,n,max_bits", REGISTRY)
+def test_every_registry_entry_at_its_own_size(agx, orc, dev, config, n, max_bits):
+    """each registered kernel configuration selected explicitly (AGX_VARIANT_REGBLOCK_BASE + id) at the size it
+    serves, under the largest modulus its arithmetic form admits and under a 30-bit one: forward in place and
+    out of place against the oracle, then (where the entry has them) inverse and fused product"""
+    batch = 3
+    for bits in (max_bits, 30):
+        plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, 1)
+        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+        q, psi, tw, pre = tabs[0]
+        rng = np.random.default_rng(config * 131 + bits)
+        x = rand_coeffs(rng, batch * n, q, hi_mult=4 if bits < 62 else 3)
+        want = orc.forward(x, q, tw, pre, n)
+        d_x, d_y = dev.to_device(x), dev.empty(x.size)
+        plan.forward(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+        assert np.array_equal(dev.to_host(d_y), want), (config, bits, "out of place")
+        assert np.array_equal(dev.to_host(d_x), x)
+        plan.forward(d_x.data_ptr(), d_x.data_ptr(), batch, dev.stream)
+        assert np.array_equal(dev.to_host(d_x), want), (config, bits, "in place")
+        plan.inverse(d_x.data_ptr(), d_x.data_ptr(), batch, dev.stream)
+        assert np.array_equal(dev.to_host(d_x), x % np.uint64(q)), (config, bits, "inverse")
+        a, b = rand_coeffs(rng, batch * n, q), rand_coeffs(rng, batch * n, q)
+        d_a, d_b, d_c, d_s = dev.to_device(a), dev.to_device(b), dev.empty(a.size), dev.empty(a.size)
+        plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), batch, dev.stream)
+        wantc = np.concatenate([_oracle_polymul(orc, a[f * n:(f + 1) * n], b[f * n:(f + 1) * n], q, psi, n) for f in range(batch)])
+        assert np.array_equal(dev.to_host(d_c), wantc), (config, bits, "polymul")
+        plan.close()
+
+
+def test_harness_binary_passes(agx):
+    """bin/ntt_harness (src/main.cpp: the reference-shaped ntt_input_kernel / fwd_ntt_kernel<0> / ntt_output_kernel mirror,
+    agx::ntt() / agx::intt(), structured known answers, schoolbook product) as a child process on the GPU"""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(agx.LIB_PATH), "..", "bin", "ntt_harness")
+    if not os.path.exists(exe):
+        agx.build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "HARNESS PASSED" in r.stdout, r.stdout[-2000:]
+
+
 def test_randomised_shapes_against_oracle(agx, orc, dev):
     """40 random (n, modulus size, primes, batch, in/out of place, lazy) forward + inverse cases:
     every size class, every arithmetic form, ragged batches"""
@@ -643,4 +736,16 @@ def test_randomised_shapes_against_oracle(agx, orc, dev):
         for p, t in enumerate(tabs):
             sl = slice(p * batch * n, (p + 1) * batch * n)
             assert np.array_equal(back[sl], x[sl] % np.uint64(t[0])), (case, n, bits, "inverse")
+        # the polynomial product of the case's input with a second random operand, c aliasing either operand at random
+        b = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=int(rng.integers(1, 5))) for t in tabs])
+        d_a, d_b, d_s = dev.to_device(x), dev.to_device(b), dev.empty(x.size)
+        alias = int(rng.integers(0, 3))
+        d_c = (dev.empty(x.size), d_a, d_b)[alias]
+        plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), batch, dev.stream)
+        c = dev.to_host(d_c)
+        for p, t in enumerate(tabs):
+            for f in range(batch):
+                sl = slice((p * batch + f) * n, (p * batch + f + 1) * n)
+                wantc = orc.schoolbook(x[sl] % np.uint64(t[0]), b[sl] % np.uint64(t[0]), t[0], n) if n <= 1024 else _oracle_polymul(orc, x[sl], b[sl], t[0], t[1], n)
+                assert np.array_equal(c[sl], wantc), (case, n, bits, "polymul", alias)
         plan.close()

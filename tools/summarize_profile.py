@@ -68,7 +68,9 @@ out = {}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     rd = counters["FETCH_SIZE"] * 1024 * 2      # gfx950: wide coalesced reads counted at half
     wr = counters["WRITE_SIZE"] * 1024
-    out = {"tag": tag, "fetch_size_kib_raw": counters["FETCH_SIZE"], "write_size_kib_raw": counters["WRITE_SIZE"],
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import agilex_ntt_amd as _agx
+    out = {"tag": tag, "kernel_source_sha16": _agx.kernel_source_sha16(), "kernel": want, "fetch_size_kib_raw": counters["FETCH_SIZE"], "write_size_kib_raw": counters["WRITE_SIZE"],
            "read_bytes_corrected": rd, "write_bytes": wr, "bytes_per_launch": rd + wr,
            "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); separate --pmc passes"}
     lines += ["## HBM traffic per launch", "", f"read {rd/2**20:.1f} MiB (FETCH_SIZE {counters['FETCH_SIZE']:.0f} KiB x2 gfx950 correction), "

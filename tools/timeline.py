@@ -6,7 +6,8 @@ boundaries, written per wave through agx_ntt_debug_set_trace_buffer) on the roof
 per phase, the mean / median / p90 duration and its share of the wave's life, plus the average number of
 waves resident per SIMD.  The stamps cost a few scalar instructions and one forced wait for the stores, so
 the traced launch is ~7 % slower than id 90; the shares are what matter.
-Usage: python tools/timeline.py [--batch B] [--out FILE.json]"""
+The trace twin and the hook live in lib/libagxntt_diag.so (`make -C agilex-ntt_amd diag`):
+Usage: AGX_NTT_LIB=agilex-ntt_amd/lib/libagxntt_diag.so python tools/timeline.py [--batch B] [--out FILE.json]"""
 import argparse
 import json
 import os
