@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -171,6 +172,14 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         const unsigned __int128 mu = ~(unsigned __int128)0 / q;  // = floor(2^128 / q) for odd q > 1
         c.mu_hi = (uint64_t)(mu >> 64);
         c.mu_lo = (uint64_t)mu;
+        if (q >= (1ull << 58)) {
+            // float slightly below 2^32 / q (reduce_final_est): scaled down by 2^-20, then rounded toward zero
+            float f = (float)(4294967296.0 / (double)q * (1.0 - 1.0 / 1048576.0));
+            if ((double)f > 4294967296.0 / (double)q * (1.0 - 1.0 / 1048576.0)) f = std::nextafterf(f, 0.0f);
+            uint32_t bits;
+            std::memcpy(&bits, &f, sizeof(bits));
+            c.est = bits;
+        }
         c.n_inv = inv_pow2_mod(p->log_n, q);
         c.n_inv_p = shoup_quotient(c.n_inv, q);
         const uint64_t* twk = tw + (size_t)k * n;

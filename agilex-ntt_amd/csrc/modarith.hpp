@@ -110,6 +110,7 @@ struct bf_consts {
     uint64_t m;      // lazy-range step: 2q (exact arithmetic) or 4q (fast arithmetic)
     uint64_t nm;     // 2^64 - m
     uint32_t one_a, one_b;  // two separate opaque_one() values (see add64_32)
+    float est_inv;          // slightly below 2^32 / q, or 0 when q < 2^58 (reduce_final_est)
 };
 
 // x in [0,2m) -> x - (x >= m ? m : 0) through the sign of x - m; needs 2m <= 2^63... see callers
@@ -233,6 +234,31 @@ struct lazy16_schedule {
     static constexpr int next(int b) { return (b + 4 > 16 ? (b - 8 > 8 ? b - 8 : 8) : b) + 4; }
 };
 
+// TAIL-FREE variant of the schedule for a transform of `total` stages: the same number of subtracting stages, but
+// placed on the stages whose parity matches `total` (from stage 2 on), so that the LAST stage never subtracts and its
+// outputs are simply below 16q; reduce_final_est then brings them home with one quotient estimate instead of
+// 2 + 2x3 conditional subtracts per butterfly.
+struct lazy16_tailfree {
+    static constexpr bool subtracts(int s, int total) { return s >= 2 && (((s ^ total) & 1) == 0); }
+    static constexpr int bound_in(int s, int total) {
+        int b = 4;
+        for (int i = 0; i < s; ++i) {
+            if (subtracts(i, total)) b = b - 8 > 8 ? b - 8 : 8;
+            b += 4;
+        }
+        return b;
+    }
+    // every stage's outputs stay within 16q, and the last stage does not subtract
+    static constexpr bool valid(int total) {
+        for (int s = 0; s < total; ++s) {
+            const int in = bound_in(s, total);
+            if (in > 16) return false;
+            if (!subtracts(s, total) && in + 4 > 16) return false;
+        }
+        return total >= 3 && !subtracts(total - 1, total);
+    }
+};
+
 // select-based conditional subtract with explicit constants
 __device__ __forceinline__ uint64_t csub_select_c(uint64_t x, uint64_t nm) {
     const uint64_t d = x + nm;
@@ -275,6 +301,29 @@ __device__ __forceinline__ uint64_t reduce_final_lazy16(uint64_t v, const bf_con
         v = csub_sign_c(v, f.q2, f.nq2);
         return csub_sign_c(v, f.q1, f.nq1);
     }
+}
+
+// [0,16q) -> [0,q) (or only [0,2q) for lazy outputs) after a tail-free 16q-lazy transform.  For q >= 2^58 the quotient
+// floor(v/q) <= 15 is estimated from the top word in single precision -- est_inv is a float slightly BELOW 2^32/q, so
+// the estimate k' is floor(v/q) or one less (never above: the remainder stays non-negative) -- then v - k' q in [0,2q)
+// and one conditional subtract finishes: 3 conversions/multiplies + 2 integer multiplies + 1 subtract step instead of
+// four subtract steps.  Smaller moduli (top word too short for the estimate) take the four steps.
+template <bool SEL>
+__device__ __forceinline__ uint64_t reduce_final_est(uint64_t v, const bf_consts& k, const final_consts& f, bool lazy_out) {
+    static_assert(SEL, "select-based conditional subtract only");
+    if (k.est_inv != 0.0f) {   // wave-uniform
+        const uint32_t kq = (uint32_t)((float)(uint32_t)(v >> 32) * k.est_inv);
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 r = __builtin_bit_cast(u32x2, mad64(kq, (uint32_t)k.nq, v));      // v + k' * (2^64 - q), low word of -q
+        r.y += kq * (uint32_t)(k.nq >> 32);                                      // ... and its high word
+        const uint64_t r64 = __builtin_bit_cast(uint64_t, r);
+        return lazy_out ? r64 : csub_select_c(r64, f.nq1);
+    }
+    v = csub_select_c(v, f.nq8);
+    v = csub_select_c(v, k.nm);          // 4q
+    if (lazy_out) return v;
+    v = csub_select_c(v, f.nq2);
+    return csub_select_c(v, f.nq1);
 }
 
 // w*d - c*q (mod 2^64) with the quotient estimate of the chosen arithmetic:

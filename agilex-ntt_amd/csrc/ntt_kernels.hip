@@ -264,7 +264,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
         if (e && (split_for(*e) < 0 || e->arith > arith_level)) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
-        static const int kDefaults[] = {90, 92, 91, 50, 39, 27, 28, 61, 40, 29, 30, 41, 31, 32, 64, 42, 33, 34, 43, 35, 36, 2};
+        static const int kDefaults[] = {93, 90, 92, 91, 50, 39, 27, 28, 61, 40, 29, 30, 41, 31, 32, 64, 42, 33, 34, 43, 35, 36, 2};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
             if (c && split_for(*c) >= 0 && c->arith <= arith_level) { e = c; break; }
@@ -379,6 +379,7 @@ hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, cons
     const rb_entry* e = rb_lookup(pv.rb.config_id);
     if (!e || !e->launch_inv || !pv.itw_rb) return hipErrorInvalidValue;
     if (pv.rb.log_split == 1 && e->launch_inv_pair) return e->launch_inv_pair(pv, in, in2, out, fl, s);
+    if (pv.rb.log_split == 0 && e->launch_inv_loop) return e->launch_inv_loop(pv, in, in2, out, fl, s);
     hipError_t err = e->launch_inv(pv, in, in2, out, fl, s);
     if (err != hipSuccess) return err;
     for (int st = pv.rb.log_split - 1; st >= 0; --st) {   // stages with a gap wider than the resident block

@@ -12,7 +12,7 @@ struct prime_consts {           // one per prime, device array
     uint64_t mu_hi, mu_lo;      // floor(2^128 / q)           (pointwise multiply)
     uint64_t n_inv, n_inv_p;    // n^-1 mod q and its precomputed quotient      (inverse, last stage)
     uint64_t w1n, w1n_p;        // inv_twiddle[1] * n^-1 mod q and its quotient  (inverse, last stage)
-    uint64_t pad;
+    uint64_t est;               // low word: float slightly below 2^32 / q for reduce_final_est, 0 when q < 2^58
 };
 
 // geometry of one register-blocked configuration (compile-time L, R mirrored at run time)

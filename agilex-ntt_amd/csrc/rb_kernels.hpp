@@ -233,6 +233,7 @@ constexpr int kOptAblateHbm = 16384;   // timing only (wrong results): every wor
 constexpr int kOptAblateLdOnly = 32768, kOptAblateStOnly = 65536;   // with kOptAblateHbm: only the loads / only the stores go to the hot frame
 constexpr int kOptNtLoad = 131072, kOptNtStore = 262144;   // non-temporal frame loads / result stores (data touched once)
 constexpr int kOptScalarBase = 1024;   // frame loads as (uniform pointer per register) + lane offset: no per-load VALU address arithmetic
+constexpr int kOptEstReduce = 524288;   // with kOptLazy16: tail-free subtract schedule + quotient-estimate final reduction
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
 // where the kOptTrace kernels write: [wave][16] words, set through agx_ntt_debug_set_trace_buffer
@@ -260,6 +261,8 @@ struct rb2_frame {
     static constexpr bool LAZY_INV = LAZY16 && (OPT & kOptLazyInv) != 0;
     static constexpr bool NT_LOAD = (OPT & kOptNtLoad) != 0;
     static constexpr bool TWA_INV = (OPT & kOptTwAheadInv) != 0 && R == 3;
+    static constexpr bool EST = LAZY16 && SEL && (OPT & kOptEstReduce) != 0;
+    static_assert(!EST || lazy16_tailfree::valid(S0 + L), "tail-free schedule must keep every stage within 16q");
     mutable uint64_t ts[12];
     uint64_t trace_wave = ~0ull;   // row of the trace buffer (default: launch-wide wave number)
     bool trace_wait_stores = true; // stamp 11 after the stores have retired (not in the streaming kernel: that would drain its prefetch)
@@ -298,7 +301,8 @@ struct rb2_frame {
     bf_consts k;
     final_consts fc;
 
-    __device__ __forceinline__ void init_consts(uint64_t q) {
+    __device__ __forceinline__ void init_consts(uint64_t q, uint64_t est = 0) {
+        k.est_inv = __uint_as_float((uint32_t)est);
         k.q = q;
         k.nq = 0 - q;
         k.m = FAST ? (q << 2) : (q << 1);
@@ -316,7 +320,8 @@ struct rb2_frame {
     // forward butterfly number `stage` of the whole transform in this frame's arithmetic
     template <int stage>
     __device__ __forceinline__ void butterfly(uint64_t& a, uint64_t& b, const twpair& w) const {
-        if constexpr (LAZY16) ct_butterfly_lazy16<SEL, lazy16_schedule::subtracts(stage), stage == S0 + L - 1>(a, b, w.x, w.y, k, fc);
+        if constexpr (EST) ct_butterfly_lazy16<SEL, lazy16_tailfree::subtracts(stage, S0 + L), false>(a, b, w.x, w.y, k, fc);
+        else if constexpr (LAZY16) ct_butterfly_lazy16<SEL, lazy16_schedule::subtracts(stage), stage == S0 + L - 1>(a, b, w.x, w.y, k, fc);
         else if constexpr (FAST) ct_butterfly_fast<SEL>(a, b, w.x, w.y, k);
         else ct_butterfly_exact(a, b, w.x, w.y, k);
     }
@@ -433,7 +438,10 @@ struct rb2_frame {
                     constexpr int stage = S0 + L - 1 - (rlo + rb);   // position in the whole transform
                     butterfly<stage>(x[r0], x[r1], w);
                     if constexpr (last_stage) {
-                        if constexpr (LAZY16) {
+                        if constexpr (EST) {
+                            x[r0] = reduce_final_est<SEL>(x[r0], k, fc, lazy_out);
+                            x[r1] = reduce_final_est<SEL>(x[r1], k, fc, lazy_out);
+                        } else if constexpr (LAZY16) {
                             x[r0] = reduce_final_lazy16<SEL>(x[r0], k, fc, lazy_out);
                             x[r1] = reduce_final_lazy16<SEL>(x[r1], k, fc, lazy_out);
                         } else {
@@ -570,10 +578,23 @@ struct rb2_frame {
     // polynomial product needs no separate pointwise pass before its inverse transform
     __device__ __forceinline__ void load_last_layout(uint64_t (&x)[C], const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2,
                                                      const barrett128& bk, int64_t base) const {
+        load_last_issue(x, in, base);
+        load_last_stage(x, in2, bk, base);
+    }
+    // first half: the frame's lane-contiguous global loads (no LDS traffic yet, so a loop kernel can put its
+    // image hand-over barrier between the two halves, behind the load latency)
+    __device__ __forceinline__ void load_last_issue(uint64_t (&x)[C], const uint64_t* __restrict__ in, int64_t base) const {
+        const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u);
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+            x[r] = (OPT & kOptNtLoad) ? __builtin_nontemporal_load(&in[base + e0 + 64u * (uint32_t)r]) : in[base + e0 + 64u * (uint32_t)r];
+    }
+    // second half: optional coefficient-wise product with in2, staging through the wave's own part of the image
+    __device__ __forceinline__ void load_last_stage(uint64_t (&x)[C], const uint64_t* __restrict__ in2, const barrett128& bk, int64_t base) const {
         const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
 #pragma unroll
         for (int r = 0; r < C; ++r) {
-            uint64_t v = (OPT & kOptNtLoad) ? __builtin_nontemporal_load(&in[base + e0 + 64u * (uint32_t)r]) : in[base + e0 + 64u * (uint32_t)r];
+            uint64_t v = x[r];
             if (in2) {   // wave-uniform
                 const uint64_t u = (OPT & kOptNtLoad) ? __builtin_nontemporal_load(&in2[base + e0 + 64u * (uint32_t)r]) : in2[base + e0 + 64u * (uint32_t)r];
                 v = mul_mod_barrett(reduce_4q(v, k.q, k.q << 1), reduce_4q(u, k.q, k.q << 1), bk);
@@ -603,7 +624,7 @@ struct rb2_frame {
     const uint64_t poly = fx >> split_log;                                                        \
     f.blk = (uint32_t)(fx & ((1u << split_log) - 1u));                                            \
     f.split_log = split_log;                                                                      \
-    f.init_consts(consts[prime].q);                                                               \
+    f.init_consts(consts[prime].q, consts[prime].est);                                                               \
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds) + (size_t)slot * F::slab_elems;             \
     const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride + ((int64_t)f.blk << L)
 
@@ -738,7 +759,7 @@ fwd_rb2_stream(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     for (uint32_t it = 0;; ++it) {
         const uint32_t prime = fr / batch, poly = fr % batch;
         const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
-        f.init_consts(consts[prime].q);
+        f.init_consts(consts[prime].q, consts[prime].est);
         hooks.slot = it & 1u;
         if constexpr (PF == 1) {
             if (threadIdx.x == 0) mailbox[it & 1u] = hooks.pending + gridDim.x;      // drawn during the previous frame's last pass
@@ -770,6 +791,87 @@ fwd_rb2_stream(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     }
 }
 
+// Loop kernels: a resident grid (as many workgroups as the chip holds at once) walks over the frames with a fixed
+// stride.  A workgroup that transforms frame after frame issues the next frame's loads right behind the current
+// frame's stores, so the store drain of one frame and the load latency of the next overlap -- with one workgroup
+// per CU (n = 16384: the frame's image fills the LDS) nothing else on the CU could cover either.  The frame-to-frame
+// hand-over of the LDS image needs one bare s_barrier (no memory wait in front of it: the stores keep draining).
+struct rb2_loop_hooks {
+    bool first;
+    // every wave has finished reading the previous frame's staged results before this frame's first exchange scatters
+    template <int p> __device__ __forceinline__ void before_image_write() const {
+        if constexpr (p == 0) {
+            if (!first) __builtin_amdgcn_s_barrier();
+        }
+    }
+    template <int p> __device__ __forceinline__ void after_twiddle_issue() const {}
+    template <int p> __device__ __forceinline__ void after_exchange_sync() const {}
+    template <int p, bool last_stage_of_pass, int b> __device__ __forceinline__ void after_butterfly() const {}
+};
+
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+fwd_rb2_loop(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+             const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
+             uint32_t pairs_per_prime, uint32_t batch, uint32_t total,
+             int64_t prime_stride, int64_t poly_stride, uint32_t lazy_out) {
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;
+    constexpr int C = F::C, T = F::T;
+    F f;
+    f.tid = threadIdx.x;
+    f.blk = 0;
+    f.split_log = 0;
+    f.lazy_out = lazy_out != 0;
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    rb2_loop_hooks hooks{true};
+    for (uint32_t fr = blockIdx.x; fr < total; fr += gridDim.x) {     // wave-uniform trip count
+        const uint32_t prime = fr / batch, poly = fr % batch;
+        const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
+        f.init_consts(consts[prime].q, consts[prime].est);
+        uint64_t x[C];
+        const uint64_t* src = in + base;
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = F::NT_LOAD ? __builtin_nontemporal_load(src + (uint32_t)r * T + f.tid) : (src + (uint32_t)r * T)[f.tid];
+        f.forward(x, tw_rb + (size_t)prime * pairs_per_prime, hooks);
+        f.store_last_layout(x, out, base, true);
+        hooks.first = false;
+    }
+}
+
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+inv_rb2_loop(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint64_t* __restrict__ out,
+             const prime_consts* __restrict__ consts, const twpair* __restrict__ itw_rb,
+             uint32_t pairs_per_prime, uint32_t batch, uint32_t total, int64_t prime_stride, int64_t poly_stride) {
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;
+    constexpr int C = F::C, T = F::T;
+    F f;
+    f.tid = threadIdx.x;
+    f.blk = 0;
+    f.split_log = 0;
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    bool first = true;
+    for (uint32_t fr = blockIdx.x; fr < total; fr += gridDim.x) {
+        const uint32_t prime = fr / batch, poly = fr % batch;
+        const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
+        const prime_consts pc = consts[prime];
+        const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
+        f.init_consts(pc.q, pc.est);
+        uint64_t x[C];
+        f.load_last_issue(x, in, base);
+        // the previous frame's last exchange is read across waves: nobody may stage into the image before all have read
+        if (!first) __builtin_amdgcn_s_barrier();
+        f.load_last_stage(x, in2, bk, base);
+        f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            if constexpr (((ARITH >> 1) & kOptNtStore) != 0) __builtin_nontemporal_store(x[r], &out[base + f.tid + (uint32_t)r * T]);
+            else out[base + f.tid + (uint32_t)r * T] = x[r];
+        }
+        first = false;
+    }
+}
+
 // Forward transform of frames of 2^(L+S) coefficients by workgroups that keep 2^L of them: block
 // `blk` of a frame computes the S leading stages for its own contiguous 2^L outputs straight from
 // global memory (reading the 2^S strided partners of each coefficient, so those stages' multiplies
@@ -797,7 +899,7 @@ fwd_rb2_split(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     f.blk = (uint32_t)(fx & ((1u << split_log) - 1u));
     f.split_log = split_log;
     f.lazy_out = lazy_out != 0;
-    f.init_consts(consts[prime].q);
+    f.init_consts(consts[prime].q, consts[prime].est);
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds) + (size_t)slot * F::slab_elems;
     const int64_t frame = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
     const int64_t base = frame + ((int64_t)f.blk << L);
@@ -848,7 +950,7 @@ fwd_rb2_pair(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     const uint32_t prime = blockIdx.y;
     f.split_log = 1;
     f.lazy_out = lazy_out != 0;
-    f.init_consts(consts[prime].q);
+    f.init_consts(consts[prime].q, consts[prime].est);
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
     const int64_t frame = (int64_t)prime * prime_stride + (int64_t)blockIdx.x * poly_stride;
     const twpair* tbl = tw_rb + (size_t)prime * pairs_per_prime;
@@ -907,7 +1009,7 @@ inv_rb2_pair(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, 
     const uint32_t prime = blockIdx.y;
     f.split_log = 1;
     const prime_consts pc = consts[prime];
-    f.init_consts(pc.q);
+    f.init_consts(pc.q, pc.est);
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
     const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
     const int64_t frame = (int64_t)prime * prime_stride + (int64_t)blockIdx.x * poly_stride;
@@ -1177,6 +1279,66 @@ constexpr rb_entry make_entry2_invpair(int id) {
     rb_entry e = make_entry2<L, R, 1, ARITH, MINW>(id);
     e.init = &init_rb2_invpair_t<L, R, ARITH, MINW>;
     e.launch_inv_pair = &launch_inv_rb2_pair_t<L, R, ARITH, MINW>;
+    return e;
+}
+
+// loop kernels: grid = the workgroups the current device holds at once (MINW waves per SIMD), fixed-stride walk
+template <int L, int R, int MINW>
+hipError_t resident_workgroups(unsigned* out) {
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) *out = (unsigned)cus * (unsigned)(MINW * 256 / rb_geom<L, R>::T);
+    return e;
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t launch_rb2_loop_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    unsigned resident = 0;
+    hipError_t e = resident_workgroups<L, R, MINW>(&resident);
+    if (e != hipSuccess) return e;
+    const uint64_t total = fl.batch * pv.num_primes;
+    if (total >= (1ull << 31)) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>();
+    hipLaunchKernelGGL((fwd_rb2_loop<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, out, pv.consts, pv.tw_rb,
+                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride, (uint32_t)(fl.lazy_out ? 1 : 0));
+    return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t launch_inv_rb2_loop_t(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    unsigned resident = 0;
+    hipError_t e = resident_workgroups<L, R, MINW>(&resident);
+    if (e != hipSuccess) return e;
+    const uint64_t total = fl.batch * pv.num_primes;
+    if (total >= (1ull << 31)) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>();
+    hipLaunchKernelGGL((inv_rb2_loop<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, in2, out, pv.consts, pv.itw_rb,
+                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t init_rb2_loop_t() {
+    hipError_t e = init_rb2_invpair_t<L, R, ARITH, MINW>();
+    const int bytes = (int)rb2_lds_bytes<L, R, 1, ARITH>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_loop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2_loop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e;
+}
+
+// a second-generation entry whose forward and inverse launches are the loop kernels (split_log = 0 only; the
+// n = 2^(L+1) inverse stays the one-launch pair kernel)
+template <int L, int R, int ARITH, int MINW, bool FWD_LOOP = true>
+constexpr rb_entry make_entry_loop(int id) {
+    rb_entry e = make_entry2_invpair<L, R, ARITH, MINW>(id);
+    e.init = &init_rb2_loop_t<L, R, ARITH, MINW>;
+    if (FWD_LOOP) e.launch = &launch_rb2_loop_t<L, R, ARITH, MINW>;
+    e.launch_inv_loop = &launch_inv_rb2_loop_t<L, R, ARITH, MINW>;
     return e;
 }
 

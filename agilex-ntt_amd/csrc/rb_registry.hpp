@@ -27,6 +27,8 @@ struct rb_entry {
     bool fused_in_place_ok;   // launch_fused loads a whole frame before it stores any of it
     // n = 2^(log_local+1): whole inverse (both resident halves + the last stage) in one launch, or null
     hipError_t (*launch_inv_pair)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
+    // whole-frame inverse (log_split = 0) by a resident grid walking over the frames, or null
+    hipError_t (*launch_inv_loop)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t) = nullptr;
 };
 
 struct rb_span {

@@ -9,6 +9,7 @@ namespace AGX_TU {
 // 90 = 16q-lazy (q <= 2^60), 92 = fast (q <= 2^61), 91 = exact (q < 2^62); 66 = R = 4 in three passes at 4 waves/SIMD (A/B, within 1.5 % of 90)
 const rb_entry kEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore) << 1), 8>(90),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8>(93),   // 90 + tail-free subtract schedule and quotient-estimate final reduction
     make_entry2<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 4>(66),   // A/B: R = 4 (three passes, 4-wave workgroups) at 4 waves/SIMD, within 1.5 % of id 90
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),

@@ -167,7 +167,7 @@ def test_structured_known_answers(agx, dev, n):
 
 
 @pytest.mark.parametrize("bits", [30, 60, 61, 62])
-@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 66, 90, 91, 92])
+@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 66, 90, 91, 92, 93])
 def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     """every registered n=4096 kernel (first-generation exact; second-generation exact, fast and
     16q-lazy; the priority-raising defaults 90/91/92) against the oracle, for 30-, 60-, 61- and 62-bit moduli (the diagnostics kernels 70/83/84
@@ -177,7 +177,7 @@ def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes, inverse=False)
     if config != "default":
         # fast forms need q <= 2^61, the 16q-lazy form q <= 2^60: anything else must be refused
-        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 90) and bits >= 61)
+        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 90, 93) and bits >= 61)
         if illegal:
             with pytest.raises(agx.AgxError) as ei:
                 plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
@@ -193,15 +193,19 @@ def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     plan.close()
 
 
-@pytest.mark.parametrize("bits", [60, 61, 62])
-def test_extreme_coefficients(agx, orc, dev, bits):
+@pytest.mark.parametrize("bits,config", [(60, None), (61, None), (62, None), (60, 93), (59, 93), (58, 93), (45, 93)])
+def test_extreme_coefficients(agx, orc, dev, bits, config):
     """worst-case lazy ranges: all coefficients 4q-1 / q-1 / 0 under the largest 60-, 61- and
-    62-bit moduli (16q-lazy, fast and exact forms respectively)"""
+    62-bit moduli (16q-lazy, fast and exact forms respectively); config 93 = the tail-free schedule whose outputs
+    reach 16q before the quotient-estimate reduction, at 60/59-bit moduli (estimate path; 59 bits = the smallest
+    top words it sees), at 58 and 45 bits (q < 2^58: the four-step fallback)"""
     n = 4096
     q = orc.find_prime(bits, n)
     psi = orc.min_root(q, n)
     tw, pre = orc.make_tables(q, psi, n)
     plan = agx.Plan(n, [q], psi=[psi])
+    if config is not None:
+        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
     top = min(4 * q - 1, 2**64 - 1)
     x = np.concatenate([np.full(n, top, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64),
                         np.where(np.arange(n) % 2 == 0, np.uint64(top), np.uint64(0))])
@@ -652,11 +656,11 @@ def test_polymul_lazy_operands(agx, orc, dev):
 # (exact: 62 bits, fast: 61, 16q-lazy: 60); defaults are reached by the other tests, this one reaches the rest
 REGISTRY = [
     (2, 4096, 62), (12, 4096, 61), (13, 4096, 62), (27, 4096, 61), (28, 4096, 62), (39, 4096, 60), (50, 4096, 60),
-    (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61),
+    (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61), (93, 4096, 60),
     (29, 1024, 61), (30, 1024, 62), (40, 1024, 60), (61, 1024, 60),
     (31, 2048, 61), (32, 2048, 62), (41, 2048, 60),
     (33, 8192, 61), (34, 8192, 62), (42, 8192, 60), (64, 8192, 60),
-    (35, 16384, 61), (36, 16384, 62), (43, 16384, 60),
+    (35, 16384, 61), (36, 16384, 62), (43, 16384, 60), (57, 16384, 60), (58, 16384, 60),
     (44, 16384, 62), (45, 16384, 61), (46, 16384, 60), (47, 32768, 62), (48, 32768, 61), (49, 32768, 60),
     (51, 16384, 62), (52, 16384, 61), (53, 16384, 60), (54, 32768, 60), (55, 32768, 61), (56, 32768, 62),
 ]
@@ -689,6 +693,28 @@ def test_every_registry_entry_at_its_own_size(agx, orc, dev, config, n, max_bits
         wantc = np.concatenate([_oracle_polymul(orc, a[f * n:(f + 1) * n], b[f * n:(f + 1) * n], q, psi, n) for f in range(batch)])
         assert np.array_equal(dev.to_host(d_c), wantc), (config, bits, "polymul")
         plan.close()
+
+
+@pytest.mark.parametrize("config", [43, 57])
+def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config):
+    """the loop kernels (a resident grid of one workgroup per CU walking over the frames with a fixed stride: the n=16384
+    default inverse, and registry id 57's forward) on more frames than the chip holds workgroups, a frame count that is not
+    a multiple of the grid, two primes, in place: forward and inverse against the oracle"""
+    n, batch, primes = 16384, 333, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
+    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+    rng = np.random.default_rng(config + 1000)
+    x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
+    d = dev.to_device(x)
+    plan.forward(d.data_ptr(), d.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d), _oracle_forward_rns(orc, x, tabs, n, batch))
+    r = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
+    want = np.concatenate([orc.inverse(r[p * batch * n:(p + 1) * batch * n] % np.uint64(tabs[p][0]), tabs[p][0],
+                                       orc.make_inv_tables(tabs[p][0], tabs[p][1], n)[0], n) for p in range(primes)])
+    d_r = dev.to_device(r)
+    plan.inverse(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_r), want)
+    plan.close()
 
 
 def test_harness_binary_passes(agx):

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""tools/run_op.py -- launch ONE operation of the engine a fixed number of times (for rocprofv3 --pmc / --kernel-trace
+runs on paths bench.py's headline does not cover).
+Usage: python tools/run_op.py --op {fwd,inv,mul} [--n N --primes P --batch B --launches K --variant ID]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import agilex_ntt_amd as agx  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--op", choices=["fwd", "inv", "mul"], default="inv")
+ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--primes", type=int, default=4)
+ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--slabs", type=int, default=4)
+ap.add_argument("--launches", type=int, default=20)
+ap.add_argument("--variant", type=int, default=None, help="registry id (AGX_VARIANT_REGBLOCK_BASE + id)")
+args = ap.parse_args()
+plan = agx.Plan(args.n, agx.find_primes(60, args.n, args.primes))
+if args.variant is not None:
+    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + args.variant)
+stream = torch.cuda.current_stream().cuda_stream
+per = args.primes * args.batch * args.n
+slabs = [torch.empty(per, dtype=torch.int64, device="cuda") for _ in range(args.slabs)]
+for i, s in enumerate(slabs):
+    plan.fill_synthetic(s.data_ptr(), args.batch, i * args.batch, 42, stream)
+scratch = torch.empty(per, dtype=torch.int64, device="cuda")
+
+
+def run(i):
+    a, b = slabs[i % args.slabs], slabs[(i + 1) % args.slabs]
+    if args.op == "fwd":
+        plan.forward(a.data_ptr(), a.data_ptr(), args.batch, stream)
+    elif args.op == "inv":
+        plan.inverse(a.data_ptr(), a.data_ptr(), args.batch, stream)
+    else:
+        plan.polymul(a.data_ptr(), b.data_ptr(), a.data_ptr(), scratch.data_ptr(), args.batch, stream)
+
+
+for i in range(5):
+    run(i)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(args.launches):
+    run(i)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / args.launches
+print(f"{args.op} n={args.n} primes={args.primes} batch={args.batch}: {ms:.4f} ms per launch, {args.primes * args.batch / ms / 1e3:.2f} M units/s")
+plan.close()
