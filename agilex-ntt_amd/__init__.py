@@ -262,11 +262,13 @@ class Plan:
     def fill_synthetic(self, d_out, batch, first_poly=0, seed=42, stream=0):
         _check(lib().agx_ntt_fill_synthetic(self._h, d_out, batch, first_poly, seed, stream), "fill_synthetic")
 
-    def forward_host_stream(self, in1, in2, num_frames):
-        """host frames through this (single-modulus) plan with overlapped transfers"""
+    def forward_host_stream(self, in1, in2, num_frames, out=None):
+        """host frames through this (single-modulus) plan with overlapped transfers; `out` (optional) is a caller-owned
+        uint64 array of num_frames*n elements (a fresh np.zeros array costs a page fault per 4 KiB when it is first written)"""
         import numpy as np
 
-        out = np.zeros(num_frames * self.n, dtype=np.uint64)
+        if out is None:
+            out = np.zeros(num_frames * self.n, dtype=np.uint64)
         _check(lib().agx_ntt_forward_host_stream(self._h, _np_ptr(in1), _np_ptr(in2), _np_ptr(out), num_frames), "forward_host_stream")
         return out
 

@@ -7,9 +7,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "host_math.hpp"
@@ -226,6 +228,80 @@ int check_call(const agx_ntt_plan* plan, const void* a, const void* b, uint64_t 
 bool use_regblock(const agx_ntt_plan* plan) {
     if (plan->variant == AGX_VARIANT_LDS_RADIX2) return false;
     return plan->rb.valid();
+}
+
+// ---- staging resources of the host-pointer pipeline (agx_ntt_forward_host_stream) ------------------------------------
+constexpr size_t kStageChunkBytes = (size_t)32 << 20;
+
+struct staging_set {
+    static constexpr int kSlots = 3;
+    uint64_t *pin_in[kSlots] = {}, *pin_out[kSlots] = {}, *dev[kSlots] = {};
+    hipStream_t st[kSlots] = {};
+    hipEvent_t done[kSlots] = {};
+    size_t bytes = 0;
+    hipError_t ensure(size_t want) {
+        if (bytes >= want) return hipSuccess;
+        destroy();
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < kSlots && e == hipSuccess; ++k) {
+            e = hipHostMalloc(reinterpret_cast<void**>(&pin_in[k]), want, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pin_out[k]), want, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dev[k]), want);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) bytes = want;
+        else destroy();
+        return e;
+    }
+    void destroy() {
+        for (int k = 0; k < kSlots; ++k) {
+            if (st[k]) { (void)hipStreamSynchronize(st[k]); (void)hipStreamDestroy(st[k]); }
+            if (done[k]) (void)hipEventDestroy(done[k]);
+            if (dev[k]) (void)hipFree(dev[k]);
+            if (pin_in[k]) (void)hipHostFree(pin_in[k]);
+            if (pin_out[k]) (void)hipHostFree(pin_out[k]);
+            st[k] = nullptr; done[k] = nullptr; dev[k] = nullptr; pin_in[k] = nullptr; pin_out[k] = nullptr;
+        }
+        bytes = 0;
+    }
+};
+
+// one cached set per device, handed to one call at a time; a second concurrent call gets nullptr and builds its own
+constexpr int kPoolDevices = 64;
+std::mutex g_stage_mu[kPoolDevices];
+staging_set g_stage_pool[kPoolDevices];
+
+staging_set* acquire_staging(int device) {
+    if (device < 0 || device >= kPoolDevices) return nullptr;
+    return g_stage_mu[device].try_lock() ? &g_stage_pool[device] : nullptr;
+}
+void release_staging(int device) { g_stage_mu[device].unlock(); }
+
+unsigned stage_workers() {
+    const unsigned hc = std::thread::hardware_concurrency();
+    unsigned cap = 4;
+    if (const char* v = std::getenv("AGX_STAGE_WORKERS")) cap = (unsigned)std::max(1, std::atoi(v));   // tuning knob (tools/host_stream_bench.py)
+    return std::max(1u, std::min(cap, hc / 2));
+}
+
+template <class F>
+void parallel_for(uint64_t items, unsigned workers, F&& fn) {
+    if (workers <= 1 || items < 2) { fn(0, items); return; }
+    const unsigned t = (unsigned)std::min<uint64_t>(workers, items);
+    std::vector<std::thread> pool;
+    pool.reserve(t - 1);
+    for (unsigned w = 1; w < t; ++w) pool.emplace_back([&, w] { fn(items * w / t, items * (w + 1) / t); });
+    fn(0, items / t);
+    for (std::thread& th : pool) th.join();
+}
+
+void parallel_memcpy(void* dst, const void* src, size_t bytes, unsigned workers) {
+    const uint64_t blocks = (bytes + 4095) / 4096;      // split on page multiples
+    parallel_for(blocks, workers, [&](uint64_t lo, uint64_t hi) {
+        const size_t b0 = (size_t)lo * 4096, b1 = std::min<size_t>(bytes, (size_t)hi * 4096);
+        if (b1 > b0) std::memcpy(static_cast<char*>(dst) + b0, static_cast<const char*>(src) + b0, b1 - b0);
+    });
 }
 
 }  // namespace
@@ -512,58 +588,66 @@ int agx_ntt_forward_host_stream(const agx_ntt_plan* plan, const uint64_t* in, co
         if (src != AGX_OK) return src;
         return se == hipSuccess ? AGX_OK : hip_fail(se);
     }
-    constexpr int kSlots = 3;
-    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(num_frames, ((size_t)32 << 20) / row));
-    const uint64_t nchunks = (num_frames + chunk - 1) / chunk;
-    const int slots = (int)std::min<uint64_t>(kSlots, nchunks);
-    uint64_t *pin_in[kSlots] = {}, *pin_out[kSlots] = {}, *dev[kSlots] = {};
-    hipStream_t st[kSlots] = {};
-    hipEvent_t done[kSlots] = {};
-    hipError_t e = hipSuccess;
+    // Pipeline: 3 slots of {pinned in, pinned out, device} on 3 streams.  The ABI takes pageable host pointers, so every
+    // byte is also copied once into and once out of pinned memory by the CPU; at ~12 GiB/s per core that staging, not
+    // PCIe, is the bottleneck of a single-threaded pipeline (tools/host_stream_bench.py).  Hence: the staging copies of a
+    // chunk are split over a few worker threads, the drain of chunk c-3 runs beside the staging of chunk c, and the
+    // pinned / device slots and streams are kept in a per-device pool between calls (allocating 192 MiB of pinned memory
+    // costs more than moving 1 GiB through it).
+    staging_set* set = acquire_staging(plan->device);
+    const bool pooled = set != nullptr;
+    staging_set local;
+    if (!set) set = &local;
+    hipError_t e = set->ensure(kStageChunkBytes);
     int rc = AGX_OK;
-    for (int k = 0; k < slots && e == hipSuccess; ++k) {
-        e = hipHostMalloc(reinterpret_cast<void**>(&pin_in[k]), chunk * row, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pin_out[k]), chunk * row, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dev[k]), chunk * row);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
-    }
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(num_frames, kStageChunkBytes / row));
+    const uint64_t nchunks = (num_frames + chunk - 1) / chunk;
+    const int slots = (int)std::min<uint64_t>(staging_set::kSlots, nchunks);
+    const unsigned workers = stage_workers();
     auto frames_of = [&](uint64_t c) { return std::min<uint64_t>(chunk, num_frames - c * chunk); };
-    auto drain = [&](uint64_t c) {   // chunk c's results: pinned -> caller's buffer (ntt.cpp:628-633)
-        const int k = (int)(c % slots);
-        hipError_t de = hipEventSynchronize(done[k]);
-        if (de == hipSuccess) std::memcpy(out + c * chunk * n, pin_out[k], frames_of(c) * row);
+    auto copy_out = [&](uint64_t c) {   // chunk c's results: pinned -> caller's buffer (ntt.cpp:628-633)
+        parallel_memcpy(out + c * chunk * n, set->pin_out[c % slots], frames_of(c) * row, workers);
+    };
+    auto drain = [&](uint64_t c) {
+        hipError_t de = hipEventSynchronize(set->done[c % slots]);
+        if (de == hipSuccess) copy_out(c);
         return de;
     };
     for (uint64_t c = 0; c < nchunks && e == hipSuccess && rc == AGX_OK; ++c) {
         const int k = (int)(c % slots);
-        if (c >= (uint64_t)slots) e = drain(c - slots);
-        if (e != hipSuccess) break;
+        std::thread drainer;
+        if (c >= (uint64_t)slots) {
+            // slot k still belongs to chunk c-slots: done[k] (recorded behind its download) says its upload source
+            // pin_in[k] is free again and its results sit in pin_out[k]
+            e = hipEventSynchronize(set->done[k]);
+            if (e != hipSuccess) break;
+            drainer = std::thread([&, c] { copy_out(c - slots); });     // beside the staging of chunk c
+        }
         const uint64_t f = frames_of(c);
         const uint64_t* a = in + c * chunk * n;
         const uint64_t* b = in2 + c * chunk * n;
         if (a == b) {
-            std::memcpy(pin_in[k], a, f * row);
+            parallel_memcpy(set->pin_in[k], a, f * row, workers);
         } else {
-            for (uint64_t i = 0; i < f; ++i) {
-                std::memcpy(reinterpret_cast<char*>(pin_in[k]) + i * row, reinterpret_cast<const char*>(a) + i * row, half);
-                std::memcpy(reinterpret_cast<char*>(pin_in[k]) + i * row + half, reinterpret_cast<const char*>(b) + i * row + half, half);
-            }
+            // lower half of each frame from `in`, upper half from `in2` (src/kernel/ntt.cpp:584-590)
+            parallel_for(f, workers, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; ++i) {
+                    std::memcpy(reinterpret_cast<char*>(set->pin_in[k]) + i * row, reinterpret_cast<const char*>(a) + i * row, half);
+                    std::memcpy(reinterpret_cast<char*>(set->pin_in[k]) + i * row + half, reinterpret_cast<const char*>(b) + i * row + half, half);
+                }
+            });
         }
-        e = hipMemcpyAsync(dev[k], pin_in[k], f * row, hipMemcpyHostToDevice, st[k]);
-        if (e == hipSuccess) rc = agx_ntt_forward(plan, dev[k], dev[k], f, st[k]);
-        if (e == hipSuccess && rc == AGX_OK) e = hipMemcpyAsync(pin_out[k], dev[k], f * row, hipMemcpyDeviceToHost, st[k]);
-        if (e == hipSuccess && rc == AGX_OK) e = hipEventRecord(done[k], st[k]);
+        e = hipMemcpyAsync(set->dev[k], set->pin_in[k], f * row, hipMemcpyHostToDevice, set->st[k]);
+        if (e == hipSuccess) rc = agx_ntt_forward(plan, set->dev[k], set->dev[k], f, set->st[k]);
+        if (drainer.joinable()) drainer.join();      // pin_out[k] must be empty before this chunk's download may land in it
+        if (e == hipSuccess && rc == AGX_OK) e = hipMemcpyAsync(set->pin_out[k], set->dev[k], f * row, hipMemcpyDeviceToHost, set->st[k]);
+        if (e == hipSuccess && rc == AGX_OK) e = hipEventRecord(set->done[k], set->st[k]);
     }
     for (uint64_t c = nchunks > (uint64_t)slots ? nchunks - slots : 0; c < nchunks && e == hipSuccess && rc == AGX_OK; ++c) e = drain(c);
-    for (int k = 0; k < slots; ++k) {
-        if (st[k]) (void)hipStreamSynchronize(st[k]);
-        if (done[k]) (void)hipEventDestroy(done[k]);
-        if (st[k]) (void)hipStreamDestroy(st[k]);
-        if (dev[k]) (void)hipFree(dev[k]);
-        if (pin_in[k]) (void)hipHostFree(pin_in[k]);
-        if (pin_out[k]) (void)hipHostFree(pin_out[k]);
-    }
+    for (int k = 0; k < staging_set::kSlots; ++k)
+        if (set->st[k]) (void)hipStreamSynchronize(set->st[k]);
+    if (pooled) release_staging(plan->device);
+    else local.destroy();
     if (rc != AGX_OK) return rc;
     return e == hipSuccess ? AGX_OK : hip_fail(e);
 }
