@@ -264,7 +264,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
         if (e && (split_for(*e) < 0 || e->arith > arith_level)) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
-        static const int kDefaults[] = {93, 90, 92, 91, 50, 39, 27, 28, 61, 40, 29, 30, 41, 31, 32, 64, 42, 33, 34, 43, 35, 36, 2};
+        static const int kDefaults[] = {93, 90, 92, 91, 50, 39, 27, 28, 63, 61, 40, 29, 30, 59, 41, 31, 32, 64, 42, 33, 34, 43, 35, 36, 2};
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
             if (c && split_for(*c) >= 0 && c->arith <= arith_level) { e = c; break; }

@@ -7,9 +7,14 @@ namespace agx {
 namespace AGX_TU {
 // n = 2048: two frames per 512-thread workgroup
 const rb_entry kEntries[] = {
+    // A/B at n = 4096: one 256-thread workgroup per frame, its two 2048-halves in turn (4-wave barrier, 17 KiB image)
+    make_entry_pair<11, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 6>(94),
+    make_entry_pair<11, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 8>(95),
+    make_entry_pair<11, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptNtLoad | kOptNtStore) << 1), 8>(96),
     make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
     make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31),
     make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(41),
+    make_entry2<11, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(59),   // A/B: one frame per 256-thread workgroup (8 workgroups per CU)
 };
 }  // namespace AGX_TU
 
