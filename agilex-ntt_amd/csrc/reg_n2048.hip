@@ -11,6 +11,9 @@ const rb_entry kEntries[] = {
     make_entry_pair<11, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 6>(94),
     make_entry_pair<11, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 8>(95),
     make_entry_pair<11, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptNtLoad | kOptNtStore) << 1), 8>(96),
+    // A/B at n = 4096, out of place only: two 256-thread workgroups per frame, each recomputing the leading stage for its 2048-half
+    make_entry_split<11, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 8, 1>(97),
+    make_entry_split<11, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtStore) << 1), 8, 1>(98),
     make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
     make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31),
     make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(41),

@@ -11,6 +11,7 @@ const rb_entry kEntries[] = {
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(33),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(42),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(64),
+    make_entry2<13, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 4>(65),   // A/B: R = 4, 512-thread workgroups (8 waves), 4 waves/SIMD
 };
 }  // namespace AGX_TU
 

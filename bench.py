@@ -78,6 +78,80 @@ def cpu_baseline(target_seconds=12.0):
     }
 
 
+class PowerSampler:
+    """Socket power and shader clock of the bench GPU from amdgpu's sysfs files (hwmon power1_average/_input in microwatts,
+    pp_dpm_sclk's starred level), sampled every 20 ms by a daemon thread while the steps run.  Evidence only: whether the
+    part sits at its power cap on this instruction mix (profiles/r02a_clock_power.txt); never part of `value`."""
+
+    def __init__(self, torch, index):
+        import glob
+        import threading
+
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+        self.power_file = self.sclk_file = self.cap_file = None
+        try:
+            props = torch.cuda.get_device_properties(index)
+            bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}"
+            for dev in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(dev)).startswith(bdf):
+                    for name in ("power1_average", "power1_input"):
+                        hit = glob.glob(os.path.join(dev, "hwmon", "hwmon*", name))
+                        if hit and self.power_file is None:
+                            self.power_file = hit[0]
+                    cap = glob.glob(os.path.join(dev, "hwmon", "hwmon*", "power1_cap"))
+                    self.cap_file = cap[0] if cap else None
+                    self.sclk_file = os.path.join(dev, "pp_dpm_sclk")
+        except Exception:
+            pass
+        if self.power_file or self.sclk_file:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def _read(self):
+        w = mhz = None
+        try:
+            if self.power_file:
+                w = int(open(self.power_file).read()) / 1e6
+        except Exception:
+            pass
+        try:
+            for line in open(self.sclk_file):
+                if "*" in line:
+                    mhz = int(line.split(":")[1].strip().split("Mhz")[0])
+        except Exception:
+            pass
+        return w, mhz
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((time.perf_counter(),) + self._read())
+            self._stop.wait(0.02)
+
+    def window(self, t0, t1):
+        """samples taken in [t0, t1] (perf_counter times) -> summary dict or None"""
+        pick = [s for s in self.samples if t0 <= s[0] <= t1]
+        watts = sorted(s[1] for s in pick if s[1] is not None)
+        mhz = sorted(s[2] for s in pick if s[2] is not None)
+        if not watts and not mhz:
+            return None
+        cap = None
+        try:
+            cap = int(open(self.cap_file).read()) / 1e6 if self.cap_file else None
+        except Exception:
+            pass
+        return {"samples": len(pick), "socket_power_w_median": watts[len(watts) // 2] if watts else None,
+                "socket_power_w_max": watts[-1] if watts else None, "power_cap_w": cap,
+                "sclk_mhz_median": mhz[len(mhz) // 2] if mhz else None, "sclk_mhz_max_level": 2400,
+                "source": "amdgpu sysfs (hwmon power1_*, pp_dpm_sclk), 20 ms period, while the ramp + warm-up + timed steps ran"}
+
+    def stop(self):
+        self._stop.set()
+        if self._thread:
+            self._thread.join(timeout=1.0)
+
+
 def _timed(torch, fn, launches, warmup):
     """average duration (ms) of `launches` back-to-back calls of fn(i) after `warmup` untimed ones,
     measured with events on the launch stream"""
@@ -85,15 +159,17 @@ def _timed(torch, fn, launches, warmup):
         fn(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _timed.window = [time.perf_counter(), None]
     e0.record()
     for i in range(launches):
         fn(warmup + i)
     e1.record()
     torch.cuda.synchronize()
+    _timed.window[1] = time.perf_counter()
     return e0.elapsed_time(e1) / launches
 
 
-def secondary_lines(torch, agx, plan4096, slabs, batch, stream):
+def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None):
     """The other north_star paths on the same clock, same process, after the headline:
     n=4096 inverse, n=4096 fused poly-mul, BASELINE configs[3] per-GPU slice (n=16384, 8 primes, batch 8192,
     in place) and configs[4] per-GPU slice (n=32768 poly-mul, batch 1024).  Each entry: units/s, average
@@ -107,17 +183,21 @@ def secondary_lines(torch, agx, plan4096, slabs, batch, stream):
              "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
         if note:
             e["note"] = note
+        if sampler is not None:
+            w = sampler.window(*_timed.window)
+            if w:
+                e["power"] = {k: w[k] for k in ("samples", "socket_power_w_median", "sclk_mhz_median")}
         out.append(e)
 
     ns = len(slabs)
     units = NUM_PRIMES * batch
     # (1) n=4096 inverse, same slabs, in place (values are whatever the forward steps left: any input below 4q is legal)
-    ms = _timed(torch, lambda i: plan4096.inverse(slabs[i % ns].data_ptr(), slabs[i % ns].data_ptr(), batch, stream), 40, 8)
-    entry("inverse_n4096", f"n={N_COEFF}, {NUM_PRIMES} primes, batch {batch}, inverse NTT in place", units, 16 * N_COEFF, ms, "NTT/s", 40)
+    ms = _timed(torch, lambda i: plan4096.inverse(slabs[i % ns].data_ptr(), slabs[i % ns].data_ptr(), batch, stream), 300, 8)
+    entry("inverse_n4096", f"n={N_COEFF}, {NUM_PRIMES} primes, batch {batch}, inverse NTT in place", units, 16 * N_COEFF, ms, "NTT/s", 300)
     # (2) n=4096 fused polynomial product c = INTT(NTT(a) o NTT(b)), c aliasing a
-    ms = _timed(torch, lambda i: plan4096.polymul(slabs[i % ns].data_ptr(), slabs[(i + 1) % ns].data_ptr(), slabs[i % ns].data_ptr(), 0, batch, stream), 20, 4)
+    ms = _timed(torch, lambda i: plan4096.polymul(slabs[i % ns].data_ptr(), slabs[(i + 1) % ns].data_ptr(), slabs[i % ns].data_ptr(), 0, batch, stream), 120, 4)
     entry("polymul_n4096", f"n={N_COEFF}, {NUM_PRIMES} primes, batch {batch}, fused NTT x2 -> pointwise -> INTT in one launch (24n bytes per product)",
-          units, 24 * N_COEFF, ms, "products/s", 20,
+          units, 24 * N_COEFF, ms, "products/s", 120,
           note="three transforms per 24n bytes: bounded by VALU integer multiply issue, not HBM (DESIGN.md section 4)")
     for s in slabs:
         s.untyped_storage().resize_(0)      # give the 2 GiB back before the large slices
@@ -128,11 +208,11 @@ def secondary_lines(torch, agx, plan4096, slabs, batch, stream):
     plan3 = agx.Plan(n3, agx.find_primes(PRIME_BITS, n3, p3))
     buf = torch.empty(p3 * b3 * n3, dtype=torch.int64, device="cuda")
     plan3.fill_synthetic(buf.data_ptr(), b3, 0, 42, stream)
-    ms = _timed(torch, lambda i: plan3.forward(buf.data_ptr(), buf.data_ptr(), b3, stream), 10, 2)
+    ms = _timed(torch, lambda i: plan3.forward(buf.data_ptr(), buf.data_ptr(), b3, stream), 16, 2)
     entry("forward_n16384_config4_slice", f"n={n3}, {p3} primes, batch {b3} per GPU (BASELINE.json configs[3] / 8 GPUs), forward in place, 8 GiB",
-          p3 * b3, 16 * n3, ms, "NTT/s", 10)
-    ms = _timed(torch, lambda i: plan3.inverse(buf.data_ptr(), buf.data_ptr(), b3, stream), 10, 2)
-    entry("inverse_n16384_config4_slice", f"n={n3}, {p3} primes, batch {b3} per GPU, inverse in place, 8 GiB", p3 * b3, 16 * n3, ms, "NTT/s", 10)
+          p3 * b3, 16 * n3, ms, "NTT/s", 16)
+    ms = _timed(torch, lambda i: plan3.inverse(buf.data_ptr(), buf.data_ptr(), b3, stream), 16, 2)
+    entry("inverse_n16384_config4_slice", f"n={n3}, {p3} primes, batch {b3} per GPU, inverse in place, 8 GiB", p3 * b3, 16 * n3, ms, "NTT/s", 16)
     plan3.close()
     del buf
     torch.cuda.empty_cache()
@@ -147,12 +227,12 @@ def secondary_lines(torch, agx, plan4096, slabs, batch, stream):
         plan4.fill_synthetic(b.data_ptr(), b4, (2 * k + 1) * b4, 42, stream)
     c = torch.empty(b4 * n4, dtype=torch.int64, device="cuda")
     scratch = torch.empty(b4 * n4, dtype=torch.int64, device="cuda")
-    ms = _timed(torch, lambda i: plan4.polymul(ab[i % sets][0].data_ptr(), ab[i % sets][1].data_ptr(), c.data_ptr(), scratch.data_ptr(), b4, stream), 12, 3)
+    ms = _timed(torch, lambda i: plan4.polymul(ab[i % sets][0].data_ptr(), ab[i % sets][1].data_ptr(), c.data_ptr(), scratch.data_ptr(), b4, stream), 120, 3)
     entry("polymul_n32768_config5_slice", f"n={n4}, one {PRIME_BITS}-bit prime, batch {b4} per GPU (BASELINE.json configs[4] / 8 GPUs), "
-          "c = INTT(NTT(a) o NTT(b)), operands never modified", b4, 24 * n4, ms, "products/s", 12,
+          "c = INTT(NTT(a) o NTT(b)), operands never modified", b4, 24 * n4, ms, "products/s", 120,
           note="VALU-bound like polymul_n4096")
-    ms = _timed(torch, lambda i: plan4.forward(ab[i % sets][0].data_ptr(), c.data_ptr(), b4, stream), 12, 3)
-    entry("forward_n32768", f"n={n4}, one prime, batch {b4}, forward out of place", b4, 16 * n4, ms, "NTT/s", 12)
+    ms = _timed(torch, lambda i: plan4.forward(ab[i % sets][0].data_ptr(), c.data_ptr(), b4, stream), 300, 3)
+    entry("forward_n32768", f"n={n4}, one prime, batch {b4}, forward out of place", b4, 16 * n4, ms, "NTT/s", 300)
     plan4.close()
     return out
 
@@ -213,6 +293,8 @@ def main():
     # follow unchanged.  The first barrier here also pays RCCL's communicator set-up outside the timing.
     grp.barrier()
     torch.cuda.synchronize()
+    sampler = PowerSampler(torch, local_rank) if rank == 0 else None
+    t_busy0 = time.perf_counter() + 0.2     # skip the first 200 ms (idle -> ramp)
     ramp_steps = 0
     t_end = time.perf_counter() + args.ramp_seconds
     while time.perf_counter() < t_end:
@@ -234,6 +316,10 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0     # this rank's K steps; the slowest rank defines the job (MAX below)
+    t_busy1 = time.perf_counter()
+    power = None
+    if sampler:
+        power = sampler.window(t_busy0, t_busy1)
     grp.barrier()
     torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration over the timed region
@@ -275,8 +361,12 @@ def main():
             "algorithmic_bytes_per_launch": ntts_per_step_per_gpu * ALGO_BYTES_PER_NTT,
         },
     }
+    if power:
+        out["power"] = power
     if world == 1 and not args.no_secondary:
-        out["secondary"] = secondary_lines(torch, agx, plan, slabs, batch, stream)
+        out["secondary"] = secondary_lines(torch, agx, plan, slabs, batch, stream, sampler)
+    if sampler:
+        sampler.stop()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

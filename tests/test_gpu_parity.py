@@ -438,8 +438,43 @@ def test_empty_batch_and_errors(agx, dev):
     with pytest.raises(agx.AgxError) as ei:
         fwd_only.inverse(d.data_ptr(), d.data_ptr(), 1, dev.stream)
     assert ei.value.status == 9
+    # poly-mul: a size without a one-launch kernel needs caller scratch (NULL -> 1), scratch must be distinct (-> 5)
+    big = agx.Plan(16384, [agx.find_primes(60, 16384)[0]])
+    e = dev.empty(16384)
+    for scratch, status in ((0, 1), (e.data_ptr(), 5)):
+        with pytest.raises(agx.AgxError) as ei:
+            big.polymul(e.data_ptr(), e.data_ptr(), e.data_ptr(), scratch, 1, dev.stream)
+        assert ei.value.status == status
+    # forward-only plans have no product either; pointwise / fill validate their pointers like the transforms do
+    with pytest.raises(agx.AgxError) as ei:
+        fwd_only.polymul(d.data_ptr(), d.data_ptr(), d.data_ptr(), 0, 1, dev.stream)
+    assert ei.value.status == 9
+    with pytest.raises(agx.AgxError) as ei:
+        plan.pointwise(d.data_ptr(), 0, d.data_ptr(), 1, dev.stream)
+    assert ei.value.status == 1
+    with pytest.raises(agx.AgxError) as ei:
+        plan.fill_synthetic(0, 1, 0, 42, dev.stream)
+    assert ei.value.status == 1
     plan.close()
     fwd_only.close()
+    big.close()
+
+
+def test_one_shot_plan_cache_follows_the_callers_tables(agx, orc):
+    """agx_ntt_forward_host keeps the plan of its last call: repeating a call reuses it, and a call with another root
+    (same n and modulus, different tables), another modulus or another n must NOT -- each result against the oracle"""
+    rng = np.random.default_rng(77)
+    n = 1024
+    q = orc.find_prime(30, n)
+    psi1 = orc.min_root(q, n)
+    psi2 = pow(psi1, 3, q)                      # another primitive 2n-th root (3 is odd)
+    cases = [(n, q, psi1), (n, q, psi1), (n, q, psi2), (n, orc.find_prime(30, n, 1), None), (2048, orc.find_prime(60, 2048), None), (n, q, psi1)]
+    for (nn, qq, psi) in cases:
+        psi = psi if psi is not None else orc.min_root(qq, nn)
+        tw, pre = orc.make_tables(qq, psi, nn)
+        x = rand_coeffs(rng, 5 * nn, qq)
+        got = agx.forward_host(x, x, qq, tw, pre, nn, 5)
+        assert np.array_equal(got, orc.forward(x, qq, tw, pre, nn)), (nn, qq, psi)
 
 
 def test_fill_synthetic_is_shard_invariant(agx, dev):
@@ -714,6 +749,30 @@ def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config):
     d_r = dev.to_device(r)
     plan.inverse(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
     assert np.array_equal(dev.to_host(d_r), want)
+    plan.close()
+
+
+@pytest.mark.parametrize("n,config,batch", [(32768, None, 1100), (16384, 53, 2100)])
+def test_pair_kernels_on_many_frames(agx, orc, dev, n, config, batch):
+    """the two-halves-in-turn kernels (n=32768: default in-place forward and one-launch inverse; n=16384: registry id 53) on
+    several rounds of workgroups per CU: forward in place and inverse against the oracle.  (A loop form of these kernels was
+    measured and dropped: the loop state pushes their already spilling register allocation from 76 to 228 bytes of scratch
+    per lane, -19 % at n=32768.)"""
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, 1)
+    if config is not None:
+        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+    q, psi, tw, pre = tabs[0]
+    rng = np.random.default_rng(n + batch)
+    x = rand_coeffs(rng, batch * n, q, hi_mult=4)
+    d = dev.to_device(x)
+    plan.forward(d.data_ptr(), d.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d), orc.forward(x, q, tw, pre, n))
+    plan.inverse(d.data_ptr(), d.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d), x % np.uint64(q))
+    r = rand_coeffs(rng, batch * n, q, hi_mult=4)
+    d_r = dev.to_device(r)
+    plan.inverse(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_r), orc.inverse(r % np.uint64(q), q, orc.make_inv_tables(q, psi, n)[0], n))
     plan.close()
 
 
