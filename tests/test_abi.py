@@ -130,3 +130,40 @@ def test_bench_cpu_baseline_leg_runs(orc):
     assert r["kind"] == "port" and r["unit"] == "NTT/s" and r["cores"] == 2
     assert r["value"] > 1000 and r["single_core_value"] > 500
     assert bench.host_cores() >= 1
+
+
+def test_diag_header_declares_only_the_debug_hook():
+    """tools/agx_ntt_diag.h (lib/libagxntt_diag.so) adds exactly one symbol to the boundary, and the public header none of it"""
+    text = open(os.path.join(ROOT, "tools", "agx_ntt_diag.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert sorted(set(re.findall(r"\b(agx_ntt_\w+)\s*\(", text))) == ["agx_ntt_debug_set_trace_buffer"]
+    assert "agx_ntt_debug_set_trace_buffer" not in _declared_symbols()
+
+
+def test_kernel_source_hash_tracks_the_sources(agx, tmp_path):
+    """profiles/hbm_traffic.json is tied to the kernel sources by agx.kernel_source_sha16(): stable, 16 hex digits"""
+    h = agx.kernel_source_sha16()
+    assert re.fullmatch(r"[0-9a-f]{16}", h) and h == agx.kernel_source_sha16()
+
+
+def test_bench_power_sampler_reads_amdgpu_sysfs_layout(tmp_path):
+    """bench.py's PowerSampler on a fake amdgpu sysfs tree: microwatts -> watts, the starred pp_dpm_sclk level, window medians"""
+    import importlib.util
+    import time
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    hw = tmp_path / "hwmon" / "hwmon3"
+    hw.mkdir(parents=True)
+    (hw / "power1_average").write_text("1370000000\n")
+    (hw / "power1_cap").write_text("1400000000\n")
+    (tmp_path / "pp_dpm_sclk").write_text("0: 500Mhz\n1: 1744Mhz *\n2: 2400Mhz\n")
+    s = bench.PowerSampler.__new__(bench.PowerSampler)
+    s.samples, s.power_file, s.cap_file, s.sclk_file = [], str(hw / "power1_average"), str(hw / "power1_cap"), str(tmp_path / "pp_dpm_sclk")
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s.samples.append((time.perf_counter(),) + s._read())
+    w = s.window(t0, time.perf_counter())
+    assert w["socket_power_w_median"] == 1370.0 and w["power_cap_w"] == 1400.0 and w["sclk_mhz_median"] == 1744 and w["samples"] == 3
+    assert s.window(t0 - 10, t0 - 5) is None
