@@ -14,6 +14,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef AGX_POLYMUL_MAXW
+#define AGX_POLYMUL_MAXW 5
+#endif
 #ifndef AGX_TU
 #error "define AGX_TU (a per-translation-unit namespace name) before including rb_kernels.hpp"
 #endif
@@ -1046,7 +1049,7 @@ inv_rb2_pair(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, 
 // the same register layout, the product is taken there, and the inverse starts from it (no staging
 // through the image at either seam).  HBM traffic 24n bytes per product.
 template <int L, int R, int PPB, int ARITH, int MINW>
-__global__ void __launch_bounds__((1 << (L - R)) * PPB, (MINW > 5 ? 5 : MINW))   // one frame more in registers
+__global__ void __launch_bounds__((1 << (L - R)) * PPB, (MINW > AGX_POLYMUL_MAXW ? AGX_POLYMUL_MAXW : MINW))   // one frame more in registers
 polymul_rb2(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ c,
             const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb, const twpair* __restrict__ itw_rb,
             uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride) {
