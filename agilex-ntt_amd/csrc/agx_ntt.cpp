@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,8 @@ namespace agx { hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves); }
 #endif
 
 using namespace agx;
+
+constexpr uint32_t kTicketRing = 1024;   // launches of one plan that may be in flight at once on different streams
 
 struct agx_ntt_plan {
     uint32_t n = 0, log_n = 0, num_primes = 0;
@@ -39,7 +42,11 @@ struct agx_ntt_plan {
     ulonglong2* d_tw_rb_oop = nullptr;
     regblock_layout rb_fip;            // forward layout used when out == in (pair kernels), or invalid
     ulonglong2* d_tw_rb_fip = nullptr;
-    uint32_t* d_ticket = nullptr;      // {next frame, retired workgroups} of the streaming kernel (registry id 83), zero between launches
+    // Ring of {next frame, retired workgroups} pairs for the kernels that hand out frames dynamically (the n=16384 loop
+    // kernels; diag ids 83/84).  Every launch takes the next pair, and the last workgroup out zeroes it again, so launches
+    // that overlap on different streams never share a counter unless kTicketRing of them are in flight at once.
+    uint32_t* d_ticket = nullptr;
+    mutable std::atomic<uint32_t> launch_seq{0};
 };
 
 namespace {
@@ -90,7 +97,7 @@ plan_view view_of(const agx_ntt_plan* p) {
     v.rb = p->rb;
     v.tw_rb = p->d_tw_rb;
     v.itw_rb = p->d_itw_rb;
-    v.ticket = p->d_ticket;
+    v.ticket = p->d_ticket ? p->d_ticket + 2 * (p->launch_seq.fetch_add(1, std::memory_order_relaxed) % kTicketRing) : nullptr;
     return v;
 }
 
@@ -201,8 +208,8 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     }
     if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
     {
-        hipError_t te = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 2 * sizeof(uint32_t));
-        if (te == hipSuccess) te = hipMemset(p->d_ticket, 0, 2 * sizeof(uint32_t));
+        hipError_t te = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 2 * kTicketRing * sizeof(uint32_t));
+        if (te == hipSuccess) te = hipMemset(p->d_ticket, 0, 2 * kTicketRing * sizeof(uint32_t));
         if (te != hipSuccess) { free_plan(p); return hip_fail(te); }
     }
     if ((rc = upload(&p->d_tw, tw_pairs)) != AGX_OK) { free_plan(p); return rc; }

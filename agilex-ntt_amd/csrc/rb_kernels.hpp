@@ -841,6 +841,116 @@ fwd_rb2_loop(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     }
 }
 
+// Dynamic form of the loop kernels: the resident workgroups draw their next frame from a ticket counter instead of
+// walking with a fixed stride, so a CU that runs a few per cent faster simply takes more frames (the fixed stride cost
+// the forward loop kernel 4 %).  Thread 0 draws the ticket one frame ahead, right behind the frame loads -- the atomic's
+// latency hides behind them -- and hands it round the workgroup through a two-slot LDS mailbox that everybody reads
+// after the frame's own cross-wave barrier.  ticket[0] = frames handed out beyond the first round, ticket[1] = retired
+// workgroups; the last workgroup out zeroes both (the plan gives every launch its own pair from a ring).
+struct rb2_dloop_hooks {
+    bool first;
+    volatile uint32_t* mailbox;
+    uint32_t slot;
+    uint32_t next;
+    template <int p> __device__ __forceinline__ void before_image_write() const {
+        if constexpr (p == 0) {
+            if (!first) __builtin_amdgcn_s_barrier();
+        }
+    }
+    template <int p> __device__ __forceinline__ void after_twiddle_issue() const {}
+    template <int p> __device__ __forceinline__ void after_exchange_sync() {
+        if constexpr (p == 0) next = (uint32_t)__builtin_amdgcn_readfirstlane((int)mailbox[slot]);
+    }
+    template <int p, bool last_stage_of_pass, int b> __device__ __forceinline__ void after_butterfly() const {}
+};
+
+__device__ __forceinline__ void dloop_retire(uint32_t* ticket) {
+    if (threadIdx.x == 0) {
+        if (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {     // last workgroup out: reset the pair for its next launch
+            __threadfence();
+            ticket[0] = 0;
+            ticket[1] = 0;
+        }
+    }
+}
+
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+fwd_rb2_dloop(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+              const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb,
+              uint32_t pairs_per_prime, uint32_t batch, uint32_t total,
+              int64_t prime_stride, int64_t poly_stride, uint32_t lazy_out, uint32_t* __restrict__ ticket) {
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;
+    static_assert(!F::G::exchange_is_wave_local(0), "the mailbox is read behind exchange 0's workgroup barrier");
+    constexpr int C = F::C, T = F::T;
+    F f;
+    f.tid = threadIdx.x;
+    f.blk = 0;
+    f.split_log = 0;
+    f.lazy_out = lazy_out != 0;
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(f.slab + F::slab_elems);   // two words behind the image
+    rb2_dloop_hooks hooks{true, mailbox, 0, 0};
+    uint32_t fr = blockIdx.x;       // launch guarantees gridDim.x <= total
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t prime = fr / batch, poly = fr % batch;
+        const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
+        f.init_consts(consts[prime].q, consts[prime].est);
+        uint64_t x[C];
+        const uint64_t* src = in + base;
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = F::NT_LOAD ? __builtin_nontemporal_load(src + (uint32_t)r * T + f.tid) : (src + (uint32_t)r * T)[f.tid];
+        hooks.slot = it & 1u;
+        if (threadIdx.x == 0) mailbox[it & 1u] = atomicAdd(ticket, 1u) + gridDim.x;   // read by everyone behind this frame's barrier
+        f.forward(x, tw_rb + (size_t)prime * pairs_per_prime, hooks);
+        f.store_last_layout(x, out, base, true);
+        hooks.first = false;
+        fr = hooks.next;
+        if (fr >= total) break;
+    }
+    dloop_retire(ticket);
+}
+
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+inv_rb2_dloop(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint64_t* __restrict__ out,
+              const prime_consts* __restrict__ consts, const twpair* __restrict__ itw_rb,
+              uint32_t pairs_per_prime, uint32_t batch, uint32_t total, int64_t prime_stride, int64_t poly_stride,
+              uint32_t* __restrict__ ticket) {
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;
+    static_assert(!F::G::exchange_is_wave_local(0), "the mailbox is read behind the last exchange's workgroup barrier");
+    constexpr int C = F::C, T = F::T;
+    F f;
+    f.tid = threadIdx.x;
+    f.blk = 0;
+    f.split_log = 0;
+    f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
+    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(f.slab + F::slab_elems);
+    uint32_t fr = blockIdx.x;
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t prime = fr / batch, poly = fr % batch;
+        const int64_t base = (int64_t)prime * prime_stride + (int64_t)poly * poly_stride;
+        const prime_consts pc = consts[prime];
+        const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
+        f.init_consts(pc.q, pc.est);
+        uint64_t x[C];
+        f.load_last_issue(x, in, base);
+        if (threadIdx.x == 0) mailbox[it & 1u] = atomicAdd(ticket, 1u) + gridDim.x;
+        if (it) __builtin_amdgcn_s_barrier();   // every wave has read the previous frame's last exchange
+        f.load_last_stage(x, in2, bk, base);
+        f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);      // its last exchange is a workgroup barrier: the mailbox is visible behind it
+        const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)mailbox[it & 1u]);
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            if constexpr (((ARITH >> 1) & kOptNtStore) != 0) __builtin_nontemporal_store(x[r], &out[base + f.tid + (uint32_t)r * T]);
+            else out[base + f.tid + (uint32_t)r * T] = x[r];
+        }
+        fr = next;
+        if (fr >= total) break;
+    }
+    dloop_retire(ticket);
+}
+
 template <int L, int R, int ARITH, int MINW>
 __global__ void __launch_bounds__((1 << (L - R)), MINW)
 inv_rb2_loop(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint64_t* __restrict__ out,
@@ -1323,6 +1433,55 @@ hipError_t launch_inv_rb2_loop_t(const plan_view& pv, const uint64_t* in, const 
     hipLaunchKernelGGL((inv_rb2_loop<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, in2, out, pv.consts, pv.itw_rb,
                        pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride);
     return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t launch_rb2_dloop_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    unsigned resident = 0;
+    hipError_t e = resident_workgroups<L, R, MINW>(&resident);
+    if (e != hipSuccess) return e;
+    const uint64_t total = fl.batch * pv.num_primes;
+    if (total >= (1ull << 31) || !pv.ticket) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
+    hipLaunchKernelGGL((fwd_rb2_dloop<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, out, pv.consts, pv.tw_rb,
+                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride, (uint32_t)(fl.lazy_out ? 1 : 0), pv.ticket);
+    return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t launch_inv_rb2_dloop_t(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    unsigned resident = 0;
+    hipError_t e = resident_workgroups<L, R, MINW>(&resident);
+    if (e != hipSuccess) return e;
+    const uint64_t total = fl.batch * pv.num_primes;
+    if (total >= (1ull << 31) || !pv.ticket) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(total < resident ? total : resident);
+    const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
+    hipLaunchKernelGGL((inv_rb2_dloop<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, in2, out, pv.consts, pv.itw_rb,
+                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride, pv.ticket);
+    return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t init_rb2_dloop_t() {
+    hipError_t e = init_rb2_invpair_t<L, R, ARITH, MINW>();
+    const int bytes = (int)rb2_lds_bytes<L, R, 1, ARITH>() + 16;
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_dloop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2_dloop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e;
+}
+
+// forward and inverse by the dynamic loop kernels (FWD / INV select which of the two; the other stays one workgroup per frame)
+template <int L, int R, int ARITH, int MINW, bool FWD, bool INV>
+constexpr rb_entry make_entry_dloop(int id) {
+    rb_entry e = make_entry2_invpair<L, R, ARITH, MINW>(id);
+    e.init = &init_rb2_dloop_t<L, R, ARITH, MINW>;
+    if (FWD) e.launch = &launch_rb2_dloop_t<L, R, ARITH, MINW>;
+    if (INV) e.launch_inv_loop = &launch_inv_rb2_dloop_t<L, R, ARITH, MINW>;
+    return e;
 }
 
 template <int L, int R, int ARITH, int MINW>

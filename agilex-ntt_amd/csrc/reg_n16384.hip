@@ -10,12 +10,14 @@ namespace AGX_TU {
 const rb_entry kEntries[] = {
     make_entry2_invpair<14, 4, 0 | (kOptPad << 1), 4>(36),
     make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect) << 1), 4>(35),
-    // 43 (default): one workgroup per frame forward; inverse by the loop kernel (+9 % at 32,768 frames: its long direct-store
-    // tail overlaps the next frame's loads); 57: forward by the loop kernel too (A/B: -4 %, static partitioning costs more
-    // than the overlap wins); 58: neither (the round-1 default)
-    make_entry_loop<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 4, false>(43),
+    // 43 (default): forward one workgroup per frame; inverse by the dynamic loop kernel (a resident grid drawing frames from a
+    // ticket counter: its long direct-store tail overlaps the next frame's loads; +10.6 % at config 4's 65,536 frames).
+    // A/B: 37 forward by the dynamic loop kernel too (-2.8 %: the hand-over barrier costs the forward more than the overlap wins),
+    // 57 both by the fixed-stride loop kernels (forward -4 %, inverse +7.6 %), 58 neither (the round-1 default)
+    make_entry_dloop<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 4, false, true>(43),
+    make_entry_dloop<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 4, true, true>(37),
+    make_entry_loop<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 4>(57),
     make_entry2_invpair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 4>(58),
-    make_entry_loop<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 4>(57),   // resident grid walking over the frames
     make_entry_pair<14, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptNtLoad | kOptNtStore) << 1), 4>(54),
     make_entry_pair<14, 4, 1 | ((kOptPad | kOptSelect) << 1), 4>(55),
     make_entry_pair<14, 4, 0 | (kOptPad << 1), 4>(56),

@@ -695,7 +695,7 @@ REGISTRY = [
     (29, 1024, 61), (30, 1024, 62), (40, 1024, 60), (61, 1024, 60), (62, 1024, 60), (63, 1024, 60),
     (31, 2048, 61), (32, 2048, 62), (41, 2048, 60), (59, 2048, 60), (94, 4096, 60), (95, 4096, 60), (96, 4096, 60),
     (33, 8192, 61), (34, 8192, 62), (42, 8192, 60), (64, 8192, 60),
-    (35, 16384, 61), (36, 16384, 62), (43, 16384, 60), (57, 16384, 60), (58, 16384, 60),
+    (35, 16384, 61), (36, 16384, 62), (43, 16384, 60), (57, 16384, 60), (58, 16384, 60), (37, 16384, 60),
     (44, 16384, 62), (45, 16384, 61), (46, 16384, 60), (47, 32768, 62), (48, 32768, 61), (49, 32768, 60),
     (51, 16384, 62), (52, 16384, 61), (53, 16384, 60), (54, 32768, 60), (55, 32768, 61), (56, 32768, 62),
 ]
@@ -730,10 +730,10 @@ def test_every_registry_entry_at_its_own_size(agx, orc, dev, config, n, max_bits
         plan.close()
 
 
-@pytest.mark.parametrize("config", [43, 57])
+@pytest.mark.parametrize("config", [43, 57, 37])
 def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config):
-    """the loop kernels (a resident grid of one workgroup per CU walking over the frames with a fixed stride: the n=16384
-    default inverse, and registry id 57's forward) on more frames than the chip holds workgroups, a frame count that is not
+    """the loop kernels (a resident grid of one workgroup per CU walking over the frames -- 43: the n=16384 default, inverse by
+    the ticket-drawing loop kernel; 37: forward too; 57: both with a fixed stride) on more frames than the chip holds workgroups, a frame count that is not
     a multiple of the grid, two primes, in place: forward and inverse against the oracle"""
     n, batch, primes = 16384, 333, 2
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
@@ -749,6 +749,33 @@ def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config):
     d_r = dev.to_device(r)
     plan.inverse(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
     assert np.array_equal(dev.to_host(d_r), want)
+    plan.close()
+
+
+def test_dynamic_loop_kernels_on_two_streams_of_one_plan(agx, orc, dev):
+    """the ticket-drawing loop kernels (registry id 37) launched back to back on two streams of ONE plan, so that launches
+    overlap: every launch takes its own ticket pair from the plan's ring, so both results must be right, repeatedly"""
+    import torch
+
+    n, batch = 16384, 700
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, 1)
+    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + 37)
+    q, psi, tw, pre = tabs[0]
+    rng = np.random.default_rng(3737)
+    xa, xb = rand_coeffs(rng, batch * n, q), rand_coeffs(rng, batch * n, q)
+    wa, wb = orc.forward(xa, q, tw, pre, n), orc.forward(xb, q, tw, pre, n)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        da, db = dev.to_device(xa), dev.to_device(xb)
+        dev.sync()
+        plan.forward(da.data_ptr(), da.data_ptr(), batch, s1.cuda_stream)
+        plan.forward(db.data_ptr(), db.data_ptr(), batch, s2.cuda_stream)
+        plan.inverse(da.data_ptr(), da.data_ptr(), batch, s1.cuda_stream)
+        plan.inverse(db.data_ptr(), db.data_ptr(), batch, s2.cuda_stream)
+        plan.forward(da.data_ptr(), da.data_ptr(), batch, s1.cuda_stream)
+        plan.forward(db.data_ptr(), db.data_ptr(), batch, s2.cuda_stream)
+        dev.sync()
+        assert np.array_equal(dev.to_host(da), wa) and np.array_equal(dev.to_host(db), wb), rep
     plan.close()
 
 
