@@ -237,6 +237,8 @@ constexpr int kOptAblateLdOnly = 32768, kOptAblateStOnly = 65536;   // with kOpt
 constexpr int kOptNtLoad = 131072, kOptNtStore = 262144;   // non-temporal frame loads / result stores (data touched once)
 constexpr int kOptScalarBase = 1024;   // frame loads as (uniform pointer per register) + lane offset: no per-load VALU address arithmetic
 constexpr int kOptEstReduce = 524288;   // with kOptLazy16: tail-free subtract schedule + quotient-estimate final reduction
+constexpr int kOptSplitWord = 1048576;  // forward only: exchanges move the low and the high 32-bit words in turn through an image of HALF
+                                        // the size (4n bytes) -- the LDS footprint that lets R = 4 workgroups of 4 waves fill a CU (VERDICT r01 #1 ii)
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
 // where the kOptTrace kernels write: [wave][16] words, set through agx_ntt_debug_set_trace_buffer
@@ -265,6 +267,8 @@ struct rb2_frame {
     static constexpr bool NT_LOAD = (OPT & kOptNtLoad) != 0;
     static constexpr bool TWA_INV = (OPT & kOptTwAheadInv) != 0 && R == 3;
     static constexpr bool EST = LAZY16 && SEL && (OPT & kOptEstReduce) != 0;
+    static constexpr bool SPLIT = (OPT & kOptSplitWord) != 0;
+    static_assert(!SPLIT || PAD, "the split-word image uses the padded index");
     static_assert(!EST || lazy16_tailfree::valid(S0 + L), "tail-free schedule must keep every stage within 16q");
     mutable uint64_t ts[12];
     uint64_t trace_wave = ~0ull;   // row of the trace buffer (default: launch-wide wave number)
@@ -382,6 +386,25 @@ struct rb2_frame {
         else wave_lds_sync();
     }
 
+    // SPLIT: the whole exchange between passes p and p+1 through a 32-bit image -- low words out, low words in, high words
+    // out, high words in.  The image holds n words of 4 bytes; every lane is active in every step and no register is
+    // needed beyond x.  Three synchronisations instead of one: the middle one keeps anyone from overwriting low words
+    // that another thread has not read yet (between full exchanges the "a thread overwrites only what it read" rule
+    // makes that unnecessary).
+    template <int p>
+    __device__ __forceinline__ void split_exchange(uint64_t (&x)[C]) const {
+        uint32_t* w = reinterpret_cast<uint32_t*>(slab);
+        const uint32_t sb = sbase<p>(), nb = sbase<p + 1>();
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; w[join(sb, img((uint32_t)r << G::rlo(p)))] = (uint32_t)x[r]; });
+        exchange_sync<p>();
+        uint32_t lo[C];
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; lo[r] = w[join(nb, img((uint32_t)r << G::rlo(p + 1)))]; });
+        exchange_sync<p>();
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; w[join(sb, img((uint32_t)r << G::rlo(p)))] = (uint32_t)(x[r] >> 32); });
+        exchange_sync<p>();
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; x[r] = (uint64_t)lo[r] | ((uint64_t)w[join(nb, img((uint32_t)r << G::rlo(p + 1)))] << 32); });
+    }
+
     // forward passes [P0, P1): pass P0 reads the image unless it is pass 0 (x already holds the
     // pass-0 layout) and first orders the exchange that precedes it; every pass but the last
     // writes the image
@@ -412,7 +435,7 @@ struct rb2_frame {
                 static_for<0, C / 2>([&](auto J) { constexpr int j = J; late[j] = t.col[(size_t)(j + C / 2) * t.hstride]; });
             }
             hooks.template after_twiddle_issue<p>();
-            if constexpr (p > 0) {
+            if constexpr (p > 0 && !SPLIT) {
                 if constexpr (p == P0) exchange_sync<p - 1>();
                 image_read<p>(x);
                 if constexpr (2 * p + 1 < 12) stamp<2 * p + 1>(x[C - 1]);
@@ -460,11 +483,17 @@ struct rb2_frame {
                 // A thread overwrites exactly the image words it read for this pass, so no other
                 // thread can still need them: only the read side of an exchange has to be ordered.
                 hooks.template before_image_write<p>();
+                if constexpr (SPLIT) {
+                    static_assert(!SPLIT || (P0 == 0 && P1 == NP), "split-word exchanges run the whole transform in one call");
+                    split_exchange<p>(x);
+                    if constexpr (PRIO_BARRIER && !G::exchange_is_wave_local(p)) __builtin_amdgcn_s_setprio(0);
+                } else {
                 image_write<p>(x);
                 if constexpr (p < P1 - 1) {
                     exchange_sync<p>();
                     if constexpr (PRIO_BARRIER && !G::exchange_is_wave_local(p)) __builtin_amdgcn_s_setprio(0);
                     hooks.template after_exchange_sync<p>();
+                }
                 }
             }
         });
@@ -552,6 +581,27 @@ struct rb2_frame {
     // the last forward pass / before the first inverse pass a wave owns 64*C contiguous elements)
     __device__ __forceinline__ void store_last_layout(const uint64_t (&x)[C], uint64_t* __restrict__ out, int64_t base, bool live) const {
         static_assert(G::last_pass_wave_contiguous(), "store path assumes a wave-contiguous last pass");
+        if constexpr (SPLIT) {
+            uint32_t* w = reinterpret_cast<uint32_t*>(slab);
+            const uint32_t own32 = img(tid << R);
+            const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; w[join(own32, img((uint32_t)r))] = (uint32_t)x[r]; });
+            wave_lds_sync();
+            uint32_t lo[C];
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; lo[r] = w[join(s0, img(64u * (uint32_t)r))]; });
+            wave_lds_sync();
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; w[join(own32, img((uint32_t)r))] = (uint32_t)(x[r] >> 32); });
+            wave_lds_sync();
+            if (live) {
+                static_for<0, C>([&](auto Rr) {
+                    constexpr int r = Rr;
+                    const uint64_t v = (uint64_t)lo[r] | ((uint64_t)w[join(s0, img(64u * (uint32_t)r))] << 32);
+                    if constexpr ((OPT & kOptNtStore) != 0) __builtin_nontemporal_store(v, &out[base + e0 + 64u * (uint32_t)r]);
+                    else out[base + e0 + 64u * (uint32_t)r] = v;
+                });
+            }
+            return;
+        }
         const uint32_t own = img(tid << R);
         static_for<0, C>([&](auto Rr) { constexpr int r = Rr; slab[join(own, img((uint32_t)r))] = x[r]; });
         wave_lds_sync();
@@ -1239,7 +1289,8 @@ hipError_t init_rb_t() {
 
 template <int L, int R, int PPB, int ARITH>
 constexpr size_t rb2_lds_bytes() {
-    return (size_t)rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>::slab_elems * 8 * PPB;
+    using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;
+    return (size_t)F::slab_elems * (F::SPLIT ? 4 : 8) * PPB;
 }
 
 template <int L, int R, int PPB, int ARITH, int MINW>
@@ -1291,6 +1342,19 @@ constexpr rb_entry make_entry2(int id) {
                     &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_t<L, R, PPB, ARITH, MINW>,
                     (ARITH & 1) ? ((((ARITH >> 1) & kOptLazy16) != 0) ? 2 : 1) : 0,
                     &launch_inv_rb2_t<L, R, PPB, ARITH, MINW>, &launch_mul_rb2_t<L, R, PPB, ARITH, MINW>, 0, nullptr, false};
+}
+
+// forward kernel only (no inverse / fused product instantiated: the plan's inverse falls back to the radix-2 kernel)
+template <int L, int R, int PPB, int ARITH, int MINW>
+hipError_t init_rb2_fwd_only_t() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2<L, R, PPB, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)rb2_lds_bytes<L, R, PPB, ARITH>());
+}
+template <int L, int R, int PPB, int ARITH, int MINW>
+constexpr rb_entry make_entry_fwd_only(int id) {
+    return rb_entry{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, rb2_lds_bytes<L, R, PPB, ARITH>(),
+                    &build_table_t<L, R, true>, &launch_rb2_t<L, R, PPB, ARITH, MINW>, &init_rb2_fwd_only_t<L, R, PPB, ARITH, MINW>,
+                    (ARITH & 1) ? ((((ARITH >> 1) & kOptLazy16) != 0) ? 2 : 1) : 0, nullptr, nullptr, 0, nullptr, false};
 }
 
 template <int L, int R, int ARITH, int MINW, int PF>

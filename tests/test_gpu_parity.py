@@ -167,7 +167,7 @@ def test_structured_known_answers(agx, dev, n):
 
 
 @pytest.mark.parametrize("bits", [30, 60, 61, 62])
-@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 66, 90, 91, 92, 93])
+@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 66, 86, 89, 90, 91, 92, 93])
 def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     """every registered n=4096 kernel (first-generation exact; second-generation exact, fast and
     16q-lazy; the priority-raising defaults 90/91/92) against the oracle, for 30-, 60-, 61- and 62-bit moduli (the diagnostics kernels 70/83/84
@@ -177,7 +177,7 @@ def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes, inverse=False)
     if config != "default":
         # fast forms need q <= 2^61, the 16q-lazy form q <= 2^60: anything else must be refused
-        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 90, 93) and bits >= 61)
+        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 86, 89, 90, 93) and bits >= 61)
         if illegal:
             with pytest.raises(agx.AgxError) as ei:
                 plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
@@ -691,7 +691,7 @@ def test_polymul_lazy_operands(agx, orc, dev):
 # (exact: 62 bits, fast: 61, 16q-lazy: 60); defaults are reached by the other tests, this one reaches the rest
 REGISTRY = [
     (2, 4096, 62), (12, 4096, 61), (13, 4096, 62), (27, 4096, 61), (28, 4096, 62), (39, 4096, 60), (50, 4096, 60),
-    (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61), (93, 4096, 60),
+    (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61), (93, 4096, 60), (86, 4096, 60), (89, 4096, 60),
     (29, 1024, 61), (30, 1024, 62), (40, 1024, 60), (61, 1024, 60), (62, 1024, 60), (63, 1024, 60),
     (31, 2048, 61), (32, 2048, 62), (41, 2048, 60), (59, 2048, 60), (94, 4096, 60), (95, 4096, 60), (96, 4096, 60),
     (33, 8192, 61), (34, 8192, 62), (42, 8192, 60), (64, 8192, 60),
