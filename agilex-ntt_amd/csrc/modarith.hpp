@@ -126,11 +126,21 @@ __device__ __forceinline__ uint64_t csub_sign(uint64_t x, const bf_consts& k) {
 
 // x' = tx + w*y - c*q (mod 2^64), the whole right-hand side in 6 multiply-adds + 1 add:
 // the low words accumulate straight onto tx, the four cross products only matter mod 2^32
+// VAR (A/B in tools/microbench pwr, energy per butterfly): 0 = the four cross products as one v_mad_u64_u32 chain (shipped);
+// 1 = as 32-bit products (v_mul_lo_u32 + adds: more instructions, narrower results)
+template <int VAR = 0>
 __device__ __forceinline__ uint64_t fold_product(uint64_t tx, uint64_t y, uint64_t w, uint64_t c, const bf_consts& k) {
     const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
     const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32), nq0 = (uint32_t)k.nq, nq1 = (uint32_t)(k.nq >> 32);
     uint64_t acc = mad64(w0, y0, tx);
     acc = mad64(nq0, c0, acc);
+    if constexpr (VAR == 1) {
+        const uint32_t z32 = w0 * y1 + w1 * y0 + nq1 * c0 + nq0 * c1;
+        typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+        u32x2v av = __builtin_bit_cast(u32x2v, acc);
+        av.y += z32;
+        return __builtin_bit_cast(uint64_t, av);
+    }
     uint64_t z = mul64(w0, y1);
     z = mad64(w1, y0, z);
     z = mad64(nq1, c0, z);
@@ -267,7 +277,7 @@ __device__ __forceinline__ uint64_t csub_select_c(uint64_t x, uint64_t nm) {
 
 // LAST: the transform's final stage.  There tx is brought below 4q (one more subtract), so the
 // outputs are < 8q and the final reduction needs three steps per coefficient instead of four.
-template <bool SEL, bool DO_CSUB, bool LAST = false>
+template <bool SEL, bool DO_CSUB, bool LAST = false, int VAR = 0>
 __device__ __forceinline__ void ct_butterfly_lazy16(uint64_t& x, uint64_t& y, uint64_t w, uint64_t wp, const bf_consts& k,
                                                     const final_consts& f) {
     const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), p0 = (uint32_t)wp, p1 = (uint32_t)(wp >> 32);
@@ -282,7 +292,7 @@ __device__ __forceinline__ void ct_butterfly_lazy16(uint64_t& x, uint64_t& y, ui
     }
     uint64_t c = mad64(p1, y1, (uint64_t)__umulhi(y0, p1));                  // one v_mov builds the {h,0} pair
     c = add64_32(c, __umulhi(y1, p0), k.one_b);
-    const uint64_t xn = fold_product(tx, y, w, c, k);
+    const uint64_t xn = fold_product<VAR>(tx, y, w, c, k);
     y = (tx << 1) + k.m - xn;                                               // tx + 4q - Q~
     x = xn;
 }

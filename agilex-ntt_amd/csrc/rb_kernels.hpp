@@ -239,6 +239,7 @@ constexpr int kOptScalarBase = 1024;   // frame loads as (uniform pointer per re
 constexpr int kOptEstReduce = 524288;   // with kOptLazy16: tail-free subtract schedule + quotient-estimate final reduction
 constexpr int kOptSplitWord = 1048576;  // forward only: exchanges move the low and the high 32-bit words in turn through an image of HALF
                                         // the size (4n bytes) -- the LDS footprint that lets R = 4 workgroups of 4 waves fill a CU (VERDICT r01 #1 ii)
+constexpr int kOptMulLoCross = 2097152; // 16q-lazy forward butterflies: the four cross products as 32-bit v_mul_lo_u32 (energy A/B, tools/microbench pwr)
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
 // where the kOptTrace kernels write: [wave][16] words, set through agx_ntt_debug_set_trace_buffer
@@ -327,7 +328,7 @@ struct rb2_frame {
     // forward butterfly number `stage` of the whole transform in this frame's arithmetic
     template <int stage>
     __device__ __forceinline__ void butterfly(uint64_t& a, uint64_t& b, const twpair& w) const {
-        if constexpr (EST) ct_butterfly_lazy16<SEL, lazy16_tailfree::subtracts(stage, S0 + L), false>(a, b, w.x, w.y, k, fc);
+        if constexpr (EST) ct_butterfly_lazy16<SEL, lazy16_tailfree::subtracts(stage, S0 + L), false, (OPT & kOptMulLoCross) ? 1 : 0>(a, b, w.x, w.y, k, fc);
         else if constexpr (LAZY16) ct_butterfly_lazy16<SEL, lazy16_schedule::subtracts(stage), stage == S0 + L - 1>(a, b, w.x, w.y, k, fc);
         else if constexpr (FAST) ct_butterfly_fast<SEL>(a, b, w.x, w.y, k);
         else ct_butterfly_exact(a, b, w.x, w.y, k);

@@ -10,6 +10,7 @@ namespace AGX_TU {
 const rb_entry kEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore) << 1), 8>(90),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8>(93),   // 90 + tail-free subtract schedule and quotient-estimate final reduction
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptMulLoCross) << 1), 8>(87),     // A/B: 93 with the cross products as 32-bit multiplies (-3 % energy per butterfly in tools/microbench pwr)
     make_entry2<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 4>(66),   // A/B: R = 4 (three passes, 4-wave workgroups) at 4 waves/SIMD, within 1.5 % of id 90
     // A/B (forward only): R = 4, 256-thread workgroups, split-word exchanges through a 17 KiB image -> up to 8 workgroups per CU;
     // 89 / 86: register budget for 5 / 6 workgroups per CU (no look-ahead twiddle arrays: at R = 4 they alone are 64 VGPRs); measured 0.281 / 0.288 ms

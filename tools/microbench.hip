@@ -7,9 +7,15 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #include <string>
+#include <atomic>
+#include <chrono>
+#include <fstream>
+#include <thread>
+#include <dirent.h>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -230,7 +236,7 @@ static void time_bw(const char* name, size_t bytes_moved, F launch) {
 // The product's own butterfly forms (csrc/modarith.hpp) on register-resident coefficients, no
 // memory traffic inside the loop: what the VALU alone can sustain, i.e. the ceiling the NTT kernels
 // are measured against.  One radix-8 pass (12 butterflies on 8 coefficients) per iteration.
-template <int FORM, bool SGPR_TW>   // FORM 0 exact, 1 fast, 2 16q-lazy (every 12th..: 5 of 12 butterflies subtract)
+template <int FORM, bool SGPR_TW>   // FORM 0 exact, 1 fast, 2 16q-lazy (every 12th..: 5 of 12 butterflies subtract), 3 = 2 with 32-bit cross products
 __global__ void __launch_bounds__(512, 8) bf_kernel(uint64_t* out, const uint64_t* tw, uint64_t q, int iters) {
     using namespace agx;
     bf_consts k;
@@ -264,11 +270,15 @@ __global__ void __launch_bounds__(512, 8) bf_kernel(uint64_t* out, const uint64_
                 const int j = ((1 << stage) - 1 + (r0 >> (rb + 1))) % NTW;
                 if constexpr (FORM == 0) ct_butterfly_exact(x[r0], x[r1], w[j], wp[j], k);
                 else if constexpr (FORM == 1) ct_butterfly_fast<true>(x[r0], x[r1], w[j], wp[j], k);
+                else if constexpr (FORM == 3) {     // 16q-lazy with the cross products as 32-bit multiplies (energy A/B)
+                    if (stage == 1 || (stage == 2 && b == 0)) ct_butterfly_lazy16<true, true, false, 1>(x[r0], x[r1], w[j], wp[j], k, fc);
+                    else ct_butterfly_lazy16<true, false, false, 1>(x[r0], x[r1], w[j], wp[j], k, fc);
+                }
                 else if (stage == 1 || (stage == 2 && b == 0)) ct_butterfly_lazy16<true, true>(x[r0], x[r1], w[j], wp[j], k, fc);   // 5 of 12
                 else ct_butterfly_lazy16<true, false>(x[r0], x[r1], w[j], wp[j], k, fc);
             }
         }
-        if constexpr (FORM == 2) {   // keep the values inside the form's range between iterations (not counted as butterfly work)
+        if constexpr (FORM >= 2) {   // keep the values inside the form's range between iterations (not counted as butterfly work)
 #pragma unroll
             for (int r = 0; r < 8; ++r) x[r] &= 0x0fffffffffffffffull;
         }
@@ -364,7 +374,114 @@ static void run_dispatch() {
     CK(hipFree(slab));
 }
 
+// ---------------------------------------------------------------- power / clock probe
+// What the board draws and what clock it holds while ONE kind of work runs for ~1.2 s: the pure instruction loops, the
+// butterfly loop (no memory traffic), the frame-shaped copy (no arithmetic).  Socket power and shader clock come from
+// amdgpu's sysfs files of this device, sampled every 20 ms by a host thread (the same files bench.py reads).
+struct SysfsProbe {
+    std::string power_file, sclk_file;
+    double cap_w = 0;
+    explicit SysfsProbe(int dev) {
+        char bdf[64] = {0};
+        if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), dev) != hipSuccess) return;
+        std::string base = std::string("/sys/bus/pci/devices/") + bdf;
+        for (char& c : base) c = (char)tolower(c);
+        sclk_file = base + "/pp_dpm_sclk";
+        std::string hw = base + "/hwmon";
+        if (DIR* d = opendir(hw.c_str())) {
+            while (dirent* e = readdir(d)) {
+                if (strncmp(e->d_name, "hwmon", 5)) continue;
+                for (const char* name : {"power1_average", "power1_input"}) {
+                    std::string f = hw + "/" + e->d_name + "/" + name;
+                    if (power_file.empty() && std::ifstream(f).good()) power_file = f;
+                }
+                std::ifstream cap(hw + "/" + e->d_name + "/power1_cap");
+                double v;
+                if (cap >> v) cap_w = v / 1e6;
+            }
+            closedir(d);
+        }
+    }
+    void read(double& w, int& mhz) const {
+        w = 0; mhz = 0;
+        std::ifstream p(power_file);
+        double v;
+        if (p >> v) w = v / 1e6;
+        std::ifstream s(sclk_file);
+        std::string line;
+        while (std::getline(s, line))
+            if (line.find('*') != std::string::npos) { size_t c = line.find(':'); mhz = atoi(line.c_str() + c + 1); }
+    }
+};
+
+template <typename F>
+static void power_phase(const SysfsProbe& probe, const char* name, F launch, double units_per_launch, const char* unit) {
+    launch(); CK(hipDeviceSynchronize());
+    std::atomic<bool> stop{false};
+    std::vector<double> watts; std::vector<int> mhz;
+    std::thread sampler([&] {
+        std::this_thread::sleep_for(std::chrono::milliseconds(300));     // skip the ramp out of idle
+        while (!stop.load()) { double w; int m; probe.read(w, m); if (w > 0) watts.push_back(w); if (m > 0) mhz.push_back(m); std::this_thread::sleep_for(std::chrono::milliseconds(20)); }
+    });
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const auto t0 = std::chrono::steady_clock::now();
+    int launches = 0;
+    CK(hipEventRecord(e0));
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 1.2) {
+        for (int i = 0; i < 8; ++i) launch();
+        launches += 8;
+        CK(hipStreamSynchronize(0));
+    }
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    stop = true; sampler.join();
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::sort(watts.begin(), watts.end()); std::sort(mhz.begin(), mhz.end());
+    printf("  %-52s %8.1f W median (%4zu samples)  sclk %4d MHz   %9.3f %s\n", name, watts.empty() ? 0.0 : watts[watts.size() / 2], watts.size(),
+           mhz.empty() ? 0 : mhz[mhz.size() / 2], units_per_launch * launches / (ms * 1e-3) / 1e9, unit);
+}
+
+static void run_power() {
+    SysfsProbe probe(0);
+    printf("power / clock by kind of work (sysfs %s; cap %.0f W; 1.2 s per line, samples after the first 0.3 s)\n", probe.power_file.c_str(), probe.cap_w);
+    uint64_t* d_out; CK(hipMalloc(&d_out, 256 * 8 * 4 * 8 * 2));
+    const int blocks = 256 * 8, iters = 20000;    // 8 waves/SIMD of 256-thread workgroups
+    const double lane_ops = (double)blocks * 256 * iters * 16;
+    power_phase(probe, "v_add_u32 loop, 8 waves/SIMD", [&] { alu_kernel<ADD32><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
+    power_phase(probe, "v_mad_u64_u32 loop, 8 waves/SIMD", [&] { alu_kernel<MAD64><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
+    power_phase(probe, "v_mul_hi_u32 loop, 8 waves/SIMD", [&] { alu_kernel<MULHI><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
+    power_phase(probe, "v_lshl_add_u64 loop, 8 waves/SIMD", [&] { alu_kernel<LSHLADD64><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
+    power_phase(probe, "v_mad_u64_u32 loop, 2 waves/SIMD", [&] { alu_kernel<MAD64><<<256 * 2, 256>>>(d_out, iters, 12345u); }, lane_ops / 4, "G lane-ops/s");
+    CK(hipFree(d_out));
+    {
+        const uint64_t q = 1152921504606830593ull;
+        std::vector<uint64_t> h(1024);
+        uint64_t st = 42;
+        for (auto& v : h) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = st; }
+        uint64_t *d_tw, *d_o;
+        CK(hipMalloc(&d_tw, h.size() * 8)); CK(hipMalloc(&d_o, 256 * 4 * 512 * 8));
+        CK(hipMemcpy(d_tw, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+        const int bl = 256 * 4, it = 2000;
+        power_phase(probe, "exact butterflies on registers (random data), 8 waves/SIMD", [&] { bf_kernel<0, false><<<bl, 512>>>(d_o, d_tw, q, it); }, (double)bl * 512 * it * 12, "G butterflies/s");
+        power_phase(probe, "fast (8q-lazy) butterflies, same", [&] { bf_kernel<1, false><<<bl, 512>>>(d_o, d_tw, q, it); }, (double)bl * 512 * it * 12, "G butterflies/s");
+        power_phase(probe, "16q-lazy butterflies on registers (random data), 8 waves/SIMD", [&] { bf_kernel<2, false><<<bl, 512>>>(d_o, d_tw, q, it); }, (double)bl * 512 * it * 12, "G butterflies/s");
+        power_phase(probe, "16q-lazy, wave-uniform (SGPR) twiddles", [&] { bf_kernel<2, true><<<bl, 512>>>(d_o, d_tw, q, it); }, (double)bl * 512 * it * 12, "G butterflies/s");
+        power_phase(probe, "16q-lazy, cross products as 32-bit v_mul_lo_u32", [&] { bf_kernel<3, false><<<bl, 512>>>(d_o, d_tw, q, it); }, (double)bl * 512 * it * 12, "G butterflies/s");
+        std::fill(h.begin(), h.end(), 0ull);
+        CK(hipMemcpy(d_tw, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+        power_phase(probe, "the same on all-zero data and twiddles", [&] { bf_kernel<2, false><<<bl, 512>>>(d_o, d_tw, q, it); }, (double)bl * 512 * it * 12, "G butterflies/s");
+        CK(hipFree(d_tw)); CK(hipFree(d_o));
+    }
+    {
+        const size_t bytes = 2ull << 30;
+        void *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
+        CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
+        power_phase(probe, "copy, one workgroup per 32 KiB frame (no arithmetic)", [&] { copy_slab<<<(unsigned)(bytes / 32768), 256>>>((const u32x4*)a, (u32x4*)b, bytes / 32768); }, 2.0 * bytes, "GB/s read+write");
+        CK(hipFree(a)); CK(hipFree(b));
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "pwr") { run_power(); return 0; }
     if (argc > 1 && std::string(argv[1]) == "disp") { run_dispatch(); return 0; }
     bool do_alu = true, do_bw = true, do_bf = true;
     if (argc > 1 && std::string(argv[1]) == "alu") do_bw = do_bf = false;
