@@ -691,10 +691,10 @@ def test_polymul_lazy_operands(agx, orc, dev):
 # (exact: 62 bits, fast: 61, 16q-lazy: 60); defaults are reached by the other tests, this one reaches the rest
 REGISTRY = [
     (2, 4096, 62), (12, 4096, 61), (13, 4096, 62), (27, 4096, 61), (28, 4096, 62), (39, 4096, 60), (50, 4096, 60),
-    (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61), (93, 4096, 60), (86, 4096, 60), (89, 4096, 60),
+    (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61), (93, 4096, 60), (86, 4096, 60), (89, 4096, 60), (87, 4096, 60), (97, 4096, 60), (98, 4096, 60),
     (29, 1024, 61), (30, 1024, 62), (40, 1024, 60), (61, 1024, 60), (62, 1024, 60), (63, 1024, 60),
     (31, 2048, 61), (32, 2048, 62), (41, 2048, 60), (59, 2048, 60), (94, 4096, 60), (95, 4096, 60), (96, 4096, 60),
-    (33, 8192, 61), (34, 8192, 62), (42, 8192, 60), (64, 8192, 60),
+    (33, 8192, 61), (34, 8192, 62), (42, 8192, 60), (64, 8192, 60), (65, 8192, 60),
     (35, 16384, 61), (36, 16384, 62), (43, 16384, 60), (57, 16384, 60), (58, 16384, 60), (37, 16384, 60),
     (44, 16384, 62), (45, 16384, 61), (46, 16384, 60), (47, 32768, 62), (48, 32768, 61), (49, 32768, 60),
     (51, 16384, 62), (52, 16384, 61), (53, 16384, 60), (54, 32768, 60), (55, 32768, 61), (56, 32768, 62),
