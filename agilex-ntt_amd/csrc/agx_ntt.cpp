@@ -578,6 +578,10 @@ int agx_ntt_forward_host_stream(const agx_ntt_plan* plan, const uint64_t* in, co
                                 uint64_t num_frames) {
     if (!plan || !in || !in2 || !out) return AGX_ERR_NULL_POINTER;
     if (plan->num_primes != 1) return AGX_ERR_BAD_ARGUMENT;   // one modulus per stream, as the reference (ntt.cpp:143-144)
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != plan->device) return AGX_ERR_BAD_ARGUMENT;   // staging memory is allocated on the current device
+    }
     if (num_frames == 0) return AGX_OK;
     const size_t n = plan->n, row = n * sizeof(uint64_t), half = row / 2;
     if (num_frames * row <= ((size_t)4 << 20)) {
