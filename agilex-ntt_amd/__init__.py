@@ -119,16 +119,17 @@ def _np_ptr(a):
 
 
 def kernel_source_sha16():
-    """sha256[:16] over the device/host sources the library is built from (csrc/, sorted by name): ties a
-    committed PMC figure (profiles/hbm_traffic.json) to the build it was measured on"""
+    """sha256[:16] over the DEVICE sources the kernels are built from (csrc/*.hip and the headers they include, sorted by
+    name; not the host-side agx_ntt.cpp / host_math.*): ties a committed PMC figure (profiles/hbm_traffic.json) to the
+    kernels it was measured on"""
     import glob
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "**", "*"), recursive=True)):
-        if os.path.isfile(f) and f.rsplit(".", 1)[-1] in ("hip", "hpp", "cpp", "h", "s", "py"):
-            h.update(os.path.relpath(f, _HERE).encode())
-            h.update(open(f, "rb").read())
+    files = glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + [os.path.join(_HERE, "csrc", f) for f in ("rb_kernels.hpp", "rb_registry.hpp", "modarith.hpp", "ntt_kernels.hpp")]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, _HERE).encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
