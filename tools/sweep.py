@@ -26,7 +26,7 @@ ap.add_argument("--launches", type=int, default=20, help="back-to-back launches 
 ap.add_argument("--oop", action="store_true", help="time out of place (slab i -> slab i+1) instead of in place")
 args = ap.parse_args()
 N, P, B, SLABS = args.n, args.primes, args.batch, args.slabs
-ids = args.ids or [2, 5, 6, 7, 8, 9, 10, 11]
+ids = args.ids or [93, 90, 66]
 qs = agx.find_primes(60, N, P)
 plan = agx.Plan(N, qs)
 stream = torch.cuda.current_stream().cuda_stream
