@@ -195,6 +195,19 @@ __global__ void __launch_bounds__(256) copy_slab(const u32x4* __restrict__ in, u
         for (int k = 0; k < 8; ++k) o[threadIdx.x + 256 * k] = r[k];
     }
 }
+// the same frame-shaped traffic in the NTT kernel's own access width and cache policy: 512 threads, 8 x 8-byte loads and stores
+// per lane (element tid + 512 r), NT = non-temporal loads and stores, INPLACE = results overwrite the frame
+template <bool NT>
+__global__ void __launch_bounds__(512) copy_frame8(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t frames) {
+    for (size_t s = blockIdx.x; s < frames; s += gridDim.x) {
+        const uint64_t* p = in + s * 4096; uint64_t* o = out + s * 4096;
+        uint64_t r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = NT ? __builtin_nontemporal_load(p + threadIdx.x + 512 * k) : p[threadIdx.x + 512 * k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (NT) __builtin_nontemporal_store(r[k], o + threadIdx.x + 512 * k); else o[threadIdx.x + 512 * k] = r[k]; }
+    }
+}
 // reads coalesced, stores 16 B per lane at a lane stride of LS bytes (thread-contiguous runs): the
 // store shape of a register-blocked last pass that keeps 2^R consecutive coefficients per lane
 template <int LS>
@@ -476,6 +489,10 @@ static void run_power() {
         void *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
         CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
         power_phase(probe, "copy, one workgroup per 32 KiB frame (no arithmetic)", [&] { copy_slab<<<(unsigned)(bytes / 32768), 256>>>((const u32x4*)a, (u32x4*)b, bytes / 32768); }, 2.0 * bytes, "GB/s read+write");
+        const unsigned frames = (unsigned)(bytes / 32768);
+        power_phase(probe, "copy in the NTT's shape: 512 threads, 8-byte accesses, plain", [&] { copy_frame8<false><<<frames, 512>>>((const uint64_t*)a, (uint64_t*)b, frames); }, 2.0 * bytes, "GB/s read+write");
+        power_phase(probe, "the same with non-temporal loads and stores", [&] { copy_frame8<true><<<frames, 512>>>((const uint64_t*)a, (uint64_t*)b, frames); }, 2.0 * bytes, "GB/s read+write");
+        power_phase(probe, "the same, non-temporal, in place", [&] { copy_frame8<true><<<frames, 512>>>((const uint64_t*)a, (uint64_t*)a, frames); }, 2.0 * bytes, "GB/s read+write");
         CK(hipFree(a)); CK(hipFree(b));
     }
 }
