@@ -147,3 +147,28 @@ def test_forward_mt_equals_single_thread(orc):
     tw, pre = orc.make_tables(q, psi, n)
     x = orc.fill_splitmix(n * 37, 7, q)
     assert np.array_equal(orc.forward_mt(x, q, tw, pre, n, 5), orc.forward(x, q, tw, pre, n))
+
+
+def test_quotient_estimate_of_the_final_reduction_is_never_high_and_at_most_one_low():
+    """The arithmetic of reduce_final_est (csrc/modarith.hpp) restated with numpy float32: for q >= 2^58 and v in [0,16q),
+    k' = trunc(float(v >> 32) * est_inv) with est_inv = a float slightly below 2^32/q (agx_ntt.cpp: scaled by 1 - 2^-20,
+    rounded toward zero) must satisfy floor(v/q) - 1 <= k' <= floor(v/q), so that v - k'q lies in [0,2q).  Checked at every
+    multiple of q +-1, at the ends of the range and on random values, for moduli at both ends of [2^58, 2^60)."""
+    import numpy as np
+
+    rng = np.random.default_rng(5)
+    for q in (2**58 + 2**13 + 1, 2**59 - 2**20 + 1, 1152921504606830593, 2**60 - 2**14 + 1 - 2**15, 2**60 - 1):
+        d = 4294967296.0 / q * (1.0 - 1.0 / 1048576.0)
+        f = np.float32(d)
+        if float(f) > d:
+            f = np.nextafter(f, np.float32(0))
+        vs = [0, 1, 16 * q - 1, 2**64 - 1 if 16 * q > 2**64 - 1 else 16 * q - 2]
+        for k in range(1, 16):
+            vs += [k * q - 1, k * q, k * q + 1, k * q + (q >> 1)]
+        vs += [int(x) for x in rng.integers(0, 16 * q, size=20000, dtype=np.uint64)] if 16 * q < 2**64 else [int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2)) for _ in range(20000)]
+        vs = [v for v in vs if 0 <= v < min(16 * q, 2**64)]
+        hi = np.array([v >> 32 for v in vs], dtype=np.uint32)
+        kq = (hi.astype(np.float32) * f).astype(np.uint32)          # v_cvt_f32_u32 (RNE), v_mul_f32 (RNE), v_cvt_u32_f32 (truncate)
+        for v, k1 in zip(vs, kq.tolist()):
+            k = v // q
+            assert k - 1 <= k1 <= k, (q, v, k, k1)
