@@ -372,7 +372,8 @@ bool regblock_has_inverse(const regblock_layout& rb) {
 
 bool regblock_has_polymul(const regblock_layout& rb) {
     const rb_entry* e = rb_lookup(rb.config_id);
-    return e && e->launch_mul && rb.log_split == 0 && rb.log_local <= 13;   // 2^14: 1024 threads x 128 VGPRs cannot hold two frames
+    // 2^14: 1024 threads x 128 VGPRs cannot hold two frames, unless the kernel parks one of them in c's frame
+    return e && e->launch_mul && rb.log_split == 0 && (rb.log_local <= 13 || e->mul_parked);
 }
 
 hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {

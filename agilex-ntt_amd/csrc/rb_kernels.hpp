@@ -1243,6 +1243,54 @@ polymul_rb2(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint
     }
 }
 
+// The same product with only ONE frame in registers at a time: NTT(first) is parked in c's own frame (plain global
+// memory: written, and read back a few microseconds later by the same workgroup, so it is served by the XCD's L2)
+// while NTT(second) is computed, then fetched in the last pass's layout (each thread its 2^R consecutive
+// coefficients), multiplied, and the inverse starts from there.  This is what lets n = 16384 (16 coefficients per
+// thread: two frames do not fit 128 VGPRs) run the product in one launch, and what frees the smaller sizes from the
+// second frame's registers.  The host passes as `first` the operand c aliases, if any: a workgroup reads all of
+// `first` before it writes c, and `second` is then a different buffer.
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+polymul_rb2_park(const uint64_t* __restrict__ first, const uint64_t* __restrict__ second, uint64_t* __restrict__ c,
+                 const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb, const twpair* __restrict__ itw_rb,
+                 uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride) {
+    constexpr uint32_t split_log = 0;
+    constexpr int PPB = 1;
+    AGX_RB2_PROLOGUE;
+    const prime_consts pc = consts[prime];
+    const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
+    f.lazy_out = F::LAZY16;     // the Barrett product takes operands in [0,4q) when q <= 2^60
+    constexpr bool NTL = ((ARITH >> 1) & kOptNtLoad) != 0, NTS = ((ARITH >> 1) & kOptNtStore) != 0;
+    uint64_t x[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) x[r] = NTL ? __builtin_nontemporal_load(&first[base + f.tid + (uint32_t)r * T]) : first[base + f.tid + (uint32_t)r * T];
+    f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
+    f.store_last_layout(x, c, base, live);     // parked (coalesced, through the image)
+#pragma unroll
+    for (int r = 0; r < C; ++r) x[r] = NTL ? __builtin_nontemporal_load(&second[base + f.tid + (uint32_t)r * T]) : second[base + f.tid + (uint32_t)r * T];
+    __syncthreads();   // the image is reused; and every wave's parked stores have been acknowledged (the barrier waits for them)
+    f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
+    {
+        // NTT(first) back in the last pass's layout: lane-contiguous loads of the wave's own block (served by L2; the
+        // non-temporal policy bypasses this CU's L1) redistributed through the wave's part of the image
+        uint64_t z[C];
+        f.load_last_issue(z, c, base);
+        f.load_last_stage(z, nullptr, bk, base);
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = mul_mod_barrett(z[r], x[r], bk);
+    }
+    __syncthreads();   // nobody overwrites c's frame (below) before everybody has fetched its parked part
+    f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            if constexpr (NTS) __builtin_nontemporal_store(x[r], &c[base + f.tid + (uint32_t)r * T]);
+            else c[base + f.tid + (uint32_t)r * T] = x[r];
+        }
+    }
+}
+
 template <int L, int R, bool col_major = false>
 void build_table_t(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {
     using G = rb_geom<L, R>;
@@ -1326,6 +1374,25 @@ hipError_t launch_mul_rb2_t(const plan_view& pv, const uint64_t* a, const uint64
     hipLaunchKernelGGL((polymul_rb2<L, R, PPB, ARITH, MINW>), grid, dim3(G::T * PPB), lds, s, a, b, c, pv.consts,
                        pv.tw_rb, pv.itw_rb, pv.rb.pairs_per_prime, fl.batch, fl.prime_stride, fl.poly_stride);
     return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t launch_mul_park_t(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, const frame_layout& fl, hipStream_t s) {
+    using G = rb_geom<L, R>;
+    dim3 grid((unsigned)fl.batch, pv.num_primes);
+    const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>();
+    // the operand c aliases (if any) must be the one that is read completely before c's frame is written
+    const uint64_t* first = (c == b) ? b : a;
+    const uint64_t* second = (c == b) ? a : b;
+    hipLaunchKernelGGL((polymul_rb2_park<L, R, ARITH, MINW>), grid, dim3(G::T), lds, s, first, second, c, pv.consts,
+                       pv.tw_rb, pv.itw_rb, pv.rb.pairs_per_prime, fl.batch, fl.prime_stride, fl.poly_stride);
+    return hipGetLastError();
+}
+
+template <int L, int R, int ARITH, int MINW>
+hipError_t init_mul_park_t() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&polymul_rb2_park<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)rb2_lds_bytes<L, R, 1, ARITH>());
 }
 
 template <int L, int R, int PPB, int ARITH, int MINW>
@@ -1540,12 +1607,34 @@ hipError_t init_rb2_dloop_t() {
 }
 
 // forward and inverse by the dynamic loop kernels (FWD / INV select which of the two; the other stays one workgroup per frame)
-template <int L, int R, int ARITH, int MINW, bool FWD, bool INV>
+template <hipError_t (*BASE)(), int L, int R, int ARITH, int MINW>
+hipError_t init_plus_park_t() {
+    hipError_t e = BASE();
+    if (e == hipSuccess) e = init_mul_park_t<L, R, ARITH, MINW>();
+    return e;
+}
+
+// PARK: the fused product by polymul_rb2_park (one frame in registers, the other parked in c's frame)
+template <int L, int R, int ARITH, int MINW, bool FWD, bool INV, bool PARK = false>
 constexpr rb_entry make_entry_dloop(int id) {
     rb_entry e = make_entry2_invpair<L, R, ARITH, MINW>(id);
-    e.init = &init_rb2_dloop_t<L, R, ARITH, MINW>;
+    e.init = PARK ? &init_plus_park_t<&init_rb2_dloop_t<L, R, ARITH, MINW>, L, R, ARITH, MINW> : &init_rb2_dloop_t<L, R, ARITH, MINW>;
     if (FWD) e.launch = &launch_rb2_dloop_t<L, R, ARITH, MINW>;
     if (INV) e.launch_inv_loop = &launch_inv_rb2_dloop_t<L, R, ARITH, MINW>;
+    if (PARK) {
+        e.launch_mul = &launch_mul_park_t<L, R, ARITH, MINW>;
+        e.mul_parked = true;
+    }
+    return e;
+}
+
+// a plain second-generation entry whose fused product is the parked-operand kernel
+template <int L, int R, int ARITH, int MINW>
+constexpr rb_entry make_entry2_park(int id) {
+    rb_entry e = make_entry2<L, R, 1, ARITH, MINW>(id);
+    e.init = &init_plus_park_t<&init_rb2_t<L, R, 1, ARITH, MINW>, L, R, ARITH, MINW>;
+    e.launch_mul = &launch_mul_park_t<L, R, ARITH, MINW>;
+    e.mul_parked = true;
     return e;
 }
 

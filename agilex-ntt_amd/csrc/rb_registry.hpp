@@ -29,6 +29,7 @@ struct rb_entry {
     hipError_t (*launch_inv_pair)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t);
     // whole-frame inverse (log_split = 0) by a resident grid walking over the frames, or null
     hipError_t (*launch_inv_loop)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t) = nullptr;
+    bool mul_parked = false;   // launch_mul keeps one frame in registers (the other parked in c's frame): legal at every log_local
 };
 
 struct rb_span {

@@ -671,6 +671,32 @@ def test_polymul_every_fused_kernel(agx, orc, dev, n, bits):
     plan.close()
 
 
+def test_one_launch_product_at_16384_with_aliasing_and_no_scratch(agx, orc, dev):
+    """registry id 37's fused product at n=16384 (polymul_rb2_park: NTT of the operand c aliases is parked in c's own frame, the
+    other transform stays in registers): no caller scratch, c distinct / aliasing a / aliasing b, operands in [0,4q), two primes"""
+    n, batch, primes = 16384, 5, 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
+    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + 37)
+    rng = np.random.default_rng(3700)
+    a = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
+    b = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
+    want = np.empty_like(a)
+    for p, t in enumerate(tabs):
+        for f in range(batch):
+            sl = slice((p * batch + f) * n, (p * batch + f + 1) * n)
+            want[sl] = _oracle_polymul(orc, a[sl], b[sl], t[0], t[1], n)
+    d_a, d_b, d_c = dev.to_device(a), dev.to_device(b), dev.empty(a.size)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), 0, batch, dev.stream)          # scratch = NULL
+    assert np.array_equal(dev.to_host(d_c), want)
+    assert np.array_equal(dev.to_host(d_a), a) and np.array_equal(dev.to_host(d_b), b)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_a.data_ptr(), 0, batch, dev.stream)          # c aliasing a
+    assert np.array_equal(dev.to_host(d_a), want)
+    d_a = dev.to_device(a)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_b.data_ptr(), 0, batch, dev.stream)          # c aliasing b
+    assert np.array_equal(dev.to_host(d_b), want)
+    plan.close()
+
+
 def test_polymul_lazy_operands(agx, orc, dev):
     """operands anywhere in [0,4q) (the transforms' input contract) through the fused product at n=4096, 60-bit q:
     the 16q-lazy forward results feed the Barrett product unreduced"""
