@@ -1568,8 +1568,19 @@ hipError_t launch_inv_rb2_loop_t(const plan_view& pv, const uint64_t* in, const 
 }
 
 template <int L, int R, int ARITH, int MINW>
+hipError_t init_rb2_loop_t();
+
+// A launch recorded into a hipGraph would keep its ticket pair for as long as the graph lives, while eager launches keep
+// walking round the plan's ring; captured launches therefore take the fixed-stride loop kernels, which carry no state.
+inline bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+
+template <int L, int R, int ARITH, int MINW>
 hipError_t launch_rb2_dloop_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
+    if (stream_is_capturing(s)) return launch_rb2_loop_t<L, R, ARITH, MINW>(pv, in, out, fl, s);
     unsigned resident = 0;
     hipError_t e = resident_workgroups<L, R, MINW>(&resident);
     if (e != hipSuccess) return e;
@@ -1585,6 +1596,7 @@ hipError_t launch_rb2_dloop_t(const plan_view& pv, const uint64_t* in, uint64_t*
 template <int L, int R, int ARITH, int MINW>
 hipError_t launch_inv_rb2_dloop_t(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
+    if (stream_is_capturing(s)) return launch_inv_rb2_loop_t<L, R, ARITH, MINW>(pv, in, in2, out, fl, s);
     unsigned resident = 0;
     hipError_t e = resident_workgroups<L, R, MINW>(&resident);
     if (e != hipSuccess) return e;
@@ -1599,7 +1611,7 @@ hipError_t launch_inv_rb2_dloop_t(const plan_view& pv, const uint64_t* in, const
 
 template <int L, int R, int ARITH, int MINW>
 hipError_t init_rb2_dloop_t() {
-    hipError_t e = init_rb2_invpair_t<L, R, ARITH, MINW>();
+    hipError_t e = init_rb2_loop_t<L, R, ARITH, MINW>();      // (the fixed-stride loop kernels serve captured launches)
     const int bytes = (int)rb2_lds_bytes<L, R, 1, ARITH>() + 16;
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_dloop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2_dloop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -108,7 +108,8 @@ int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uin
 /* the dense forms use the [prime][batch][n] layout (prime_stride = batch*n,   */
 /* poly_stride = n).  In place (d_out == d_in) is allowed.  Asynchronous on    */
 /* `stream`; nothing is allocated or synchronised inside, so the calls can be  */
-/* captured into a hipGraph.                                                    */
+/* captured into a hipGraph (kernels that hand out frames through a counter    */
+/* switch to a stateless form while the stream is capturing).                   */
 /* ------------------------------------------------------------------------- */
 int agx_ntt_forward(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
 int agx_ntt_inverse(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);

@@ -391,12 +391,13 @@ def test_large_frames_fast_and_exact_forms(agx, orc, dev, n, bits):
     plan.close()
 
 
-def test_calls_are_graph_capturable(agx, orc, dev):
+@pytest.mark.parametrize("n,batch", [(4096, 8), (16384, 300)])
+def test_calls_are_graph_capturable(agx, orc, dev, n, batch):
     """the device-pointer calls allocate nothing and never synchronise, so a stream capture can
-    record them: forward + inverse captured once into a HIP graph, replayed on new data"""
+    record them: forward + inverse captured once into a HIP graph, replayed on new data (n=16384 with more frames than
+    workgroups: its inverse is a loop kernel, and a captured launch must take the stateless fixed-stride form)"""
     import torch
 
-    n, batch = 4096, 8
     q = agx.find_primes(60, n)[0]
     plan = agx.Plan(n, [q])
     tw, pre = orc.make_tables(q, plan.psi(0), n)
