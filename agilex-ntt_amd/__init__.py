@@ -34,6 +34,7 @@ ABI = {
     "agx_ntt_device_count": (_int, [ctypes.POINTER(_int)]),
     "agx_ntt_forward_host": (_int, [_p64, _p64, _p64, _p64, _p64, _p64, _u32, _u32]),
     "agx_ntt_forward_host_stream": (_int, [_vp, _p64, _p64, _p64, _u64]),
+    "agx_ntt_release_caches": (_int, []),
     "agx_ntt_plan_create": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64, _p64, _p64, _p64]),
     "agx_ntt_plan_create_auto": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64]),
     "agx_ntt_plan_destroy": (_int, [_vp]),

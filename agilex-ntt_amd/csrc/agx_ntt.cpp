@@ -18,12 +18,13 @@
 #include "host_math.hpp"
 #include "ntt_kernels.hpp"
 #ifdef AGX_DIAG
+#include "../../tools/agx_ntt_diag.h"
 namespace agx { hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves); }
 #endif
 
 using namespace agx;
 
-constexpr uint32_t kTicketRing = 1024;   // launches of one plan that may be in flight at once on different streams
+constexpr uint32_t kTicketSlots = 64;    // distinct streams of one plan that may run ticket-drawing kernels; further streams get the stateless kernels
 
 struct agx_ntt_plan {
     uint32_t n = 0, log_n = 0, num_primes = 0;
@@ -42,11 +43,15 @@ struct agx_ntt_plan {
     ulonglong2* d_tw_rb_oop = nullptr;
     regblock_layout rb_fip;            // forward layout used when out == in (pair kernels), or invalid
     ulonglong2* d_tw_rb_fip = nullptr;
-    // Ring of {next frame, retired workgroups} pairs for the kernels that hand out frames dynamically (the n=16384 loop
-    // kernels; diag ids 83/84).  Every launch takes the next pair, and the last workgroup out zeroes it again, so launches
-    // that overlap on different streams never share a counter unless kTicketRing of them are in flight at once.
+    // {next frame, retired workgroups} pairs for the kernels that hand out frames dynamically (the loop kernels of n >= 16384; diag
+    // ids 83/84), one pair per STREAM: launches on one stream run one after the other, and the last workgroup of a launch zeroes the
+    // pair, so a stream's launches can share one; launches on different streams get different pairs.  Only a launcher that needs a
+    // pair asks for one (plan_view::ticket).  A stream beyond the kTicketSlots-th gets none and its launches take the stateless
+    // fixed-stride kernels.  A slot is never recycled (a destroyed stream's handle may be reused by a new stream: that is still ONE
+    // stream at a time, so sharing its pair stays safe).
     uint32_t* d_ticket = nullptr;
-    mutable std::atomic<uint32_t> launch_seq{0};
+    mutable std::mutex ticket_mu;
+    mutable std::vector<hipStream_t> ticket_streams;
 };
 
 namespace {
@@ -75,6 +80,18 @@ hipError_t kernels_init_once(int device) {
     return result[device];
 }
 
+// nothing may propagate across the C boundary: std::vector / std::thread can throw inside the entry points below
+template <class F>
+int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return AGX_ERR_ALLOC;
+    } catch (...) {
+        return AGX_ERR_BAD_ARGUMENT;
+    }
+}
+
 int check_size(uint32_t n) {
     return (n >= AGX_NTT_MIN_N && n <= AGX_NTT_MAX_N && is_pow2(n)) ? AGX_OK : AGX_ERR_BAD_SIZE;
 }
@@ -84,6 +101,17 @@ int check_modulus(uint64_t q, uint32_t n) {
     if (q < 3 || (q & 1) == 0 || q >= (1ull << 62)) return AGX_ERR_BAD_MODULUS;
     if ((q - 1) % (2ull * n)) return AGX_ERR_BAD_MODULUS;
     return AGX_OK;
+}
+
+uint32_t* plan_ticket_for(void* ctx, hipStream_t s) {
+    const agx_ntt_plan* p = static_cast<const agx_ntt_plan*>(ctx);
+    if (!p->d_ticket) return nullptr;
+    std::lock_guard<std::mutex> lock(p->ticket_mu);
+    for (size_t i = 0; i < p->ticket_streams.size(); ++i)
+        if (p->ticket_streams[i] == s) return p->d_ticket + 2 * i;
+    if (p->ticket_streams.size() >= kTicketSlots) return nullptr;
+    p->ticket_streams.push_back(s);
+    return p->d_ticket + 2 * (p->ticket_streams.size() - 1);
 }
 
 plan_view view_of(const agx_ntt_plan* p) {
@@ -97,7 +125,8 @@ plan_view view_of(const agx_ntt_plan* p) {
     v.rb = p->rb;
     v.tw_rb = p->d_tw_rb;
     v.itw_rb = p->d_itw_rb;
-    v.ticket = p->d_ticket ? p->d_ticket + 2 * (p->launch_seq.fetch_add(1, std::memory_order_relaxed) % kTicketRing) : nullptr;
+    v.ticket_for = &plan_ticket_for;
+    v.ticket_ctx = const_cast<agx_ntt_plan*>(p);
     return v;
 }
 
@@ -208,8 +237,8 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     }
     if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
     {
-        hipError_t te = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 2 * kTicketRing * sizeof(uint32_t));
-        if (te == hipSuccess) te = hipMemset(p->d_ticket, 0, 2 * kTicketRing * sizeof(uint32_t));
+        hipError_t te = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 2 * kTicketSlots * sizeof(uint32_t));
+        if (te == hipSuccess) te = hipMemset(p->d_ticket, 0, 2 * kTicketSlots * sizeof(uint32_t));
         if (te != hipSuccess) { free_plan(p); return hip_fail(te); }
     }
     if ((rc = upload(&p->d_tw, tw_pairs)) != AGX_OK) { free_plan(p); return rc; }
@@ -361,7 +390,7 @@ int agx_ntt_plan_create(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, co
     if (num_primes == 0 || num_primes > 65535) return AGX_ERR_BAD_ARGUMENT;
     for (uint32_t k = 0; k < num_primes; ++k)
         if ((rc = check_modulus(moduli[k], n))) return rc;
-    return build_plan(plan, n, num_primes, moduli, nullptr, twiddles, precons, inv_twiddles, inv_precons);
+    return guarded([&] { return build_plan(plan, n, num_primes, moduli, nullptr, twiddles, precons, inv_twiddles, inv_precons); });
 }
 
 int agx_ntt_plan_create_auto(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, const uint64_t* moduli, const uint64_t* psi) {
@@ -370,17 +399,19 @@ int agx_ntt_plan_create_auto(agx_ntt_plan** plan, uint32_t n, uint32_t num_prime
     int rc = check_size(n);
     if (rc) return rc;
     if (num_primes == 0 || num_primes > 65535) return AGX_ERR_BAD_ARGUMENT;
-    std::vector<uint64_t> roots(num_primes), tw((size_t)num_primes * n), pre(tw.size()), itw(tw.size()), ipre(tw.size());
-    for (uint32_t k = 0; k < num_primes; ++k) {
-        const uint64_t q = moduli[k];
-        if ((rc = check_modulus(q, n))) return rc;
-        if (!is_prime_u64(q)) return AGX_ERR_BAD_MODULUS;
-        roots[k] = psi ? psi[k] : min_primitive_root_2n(q, n);
-        if (!is_primitive_root_2n(roots[k], q, n)) return AGX_ERR_BAD_ROOT;
-        power_tables_bitrev(q, roots[k], n, &tw[(size_t)k * n], &pre[(size_t)k * n]);
-        power_tables_bitrev(q, inv_mod(roots[k], q), n, &itw[(size_t)k * n], &ipre[(size_t)k * n]);
-    }
-    return build_plan(plan, n, num_primes, moduli, roots.data(), tw.data(), pre.data(), itw.data(), ipre.data());
+    return guarded([&]() -> int {
+        std::vector<uint64_t> roots(num_primes), tw((size_t)num_primes * n), pre(tw.size()), itw(tw.size()), ipre(tw.size());
+        for (uint32_t k = 0; k < num_primes; ++k) {
+            const uint64_t q = moduli[k];
+            if (int mrc = check_modulus(q, n)) return mrc;
+            if (!is_prime_u64(q)) return AGX_ERR_BAD_MODULUS;
+            roots[k] = psi ? psi[k] : min_primitive_root_2n(q, n);
+            if (!is_primitive_root_2n(roots[k], q, n)) return AGX_ERR_BAD_ROOT;
+            power_tables_bitrev(q, roots[k], n, &tw[(size_t)k * n], &pre[(size_t)k * n]);
+            power_tables_bitrev(q, inv_mod(roots[k], q), n, &itw[(size_t)k * n], &ipre[(size_t)k * n]);
+        }
+        return build_plan(plan, n, num_primes, moduli, roots.data(), tw.data(), pre.data(), itw.data(), ipre.data());
+    });
 }
 
 int agx_ntt_plan_destroy(agx_ntt_plan* plan) {
@@ -388,7 +419,11 @@ int agx_ntt_plan_destroy(agx_ntt_plan* plan) {
     return AGX_OK;
 }
 
+static int plan_set_variant_impl(agx_ntt_plan* plan, int variant);
 int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant) {
+    return guarded([&] { return plan_set_variant_impl(plan, variant); });
+}
+static int plan_set_variant_impl(agx_ntt_plan* plan, int variant) {
     if (!plan) return AGX_ERR_NULL_POINTER;
     int config_id = -1;
     if (variant >= AGX_VARIANT_REGBLOCK_BASE) {
@@ -574,8 +609,20 @@ int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t b
 // (src/kernel/ntt.cpp:508-640).  Three slots of pinned staging + device memory rotate over three
 // streams: while slot k computes, slot k+1 uploads and the host thread assembles slot k+2
 // (lower half of each frame from `in`, upper half from `in2`, src/kernel/ntt.cpp:584-590).
+static int forward_host_stream_impl(const agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2, uint64_t* out, uint64_t num_frames);
+
 int agx_ntt_forward_host_stream(const agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2, uint64_t* out,
                                 uint64_t num_frames) {
+    try {      // std::thread / std::vector inside may throw: nothing crosses the C boundary
+        return forward_host_stream_impl(plan, in, in2, out, num_frames);
+    } catch (const std::bad_alloc&) {
+        return AGX_ERR_ALLOC;
+    } catch (...) {
+        return AGX_ERR_BAD_ARGUMENT;
+    }
+}
+
+static int forward_host_stream_impl(const agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2, uint64_t* out, uint64_t num_frames) {
     if (!plan || !in || !in2 || !out) return AGX_ERR_NULL_POINTER;
     if (plan->num_primes != 1) return AGX_ERR_BAD_ARGUMENT;   // one modulus per stream, as the reference (ntt.cpp:143-144)
     {
@@ -665,16 +712,16 @@ int agx_ntt_forward_host_stream(const agx_ntt_plan* plan, const uint64_t* in, co
 
 // One-shot calls usually repeat with the same (n, modulus, tables): building a plan verifies every table
 // entry (a 128-bit divide each) and uploads four tables, which costs tens of milliseconds, so the last
-// plan is kept and reused while the caller's tables still compare equal word for word.
+// plan of each device is kept and reused while the caller's tables still compare equal word for word.
+// One slot and one lock PER DEVICE: calls on different GPUs neither evict each other's plan nor serialise.
 namespace {
 struct oneshot_cache {
     std::mutex mu;
     agx_ntt_plan* plan = nullptr;
-    int device = -1;
     uint64_t q = 0;
     std::vector<uint64_t> tw, pre;     // host copies of the tables the cached plan was built from
 };
-oneshot_cache g_oneshot;
+oneshot_cache g_oneshot[kPoolDevices];
 }  // namespace
 
 int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
@@ -687,21 +734,61 @@ int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t
     if (num_frames == 0) return AGX_OK;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return AGX_ERR_NO_DEVICE;
-    std::lock_guard<std::mutex> lock(g_oneshot.mu);    // one-shot calls are synchronous; they also serialise
-    oneshot_cache& c = g_oneshot;
-    const bool hit = c.plan && c.device == dev && c.plan->n == n && c.q == modulus[0] &&
-                     std::memcmp(c.tw.data(), twiddles, (size_t)n * 8) == 0 && std::memcmp(c.pre.data(), precons, (size_t)n * 8) == 0;
-    if (!hit) {
-        agx_ntt_plan* plan = nullptr;
-        if ((rc = build_plan(&plan, n, 1, modulus, nullptr, twiddles, precons, nullptr, nullptr))) return rc;
-        if (c.plan && c.device == dev) free_plan(c.plan);   // (a plan of another device is left to that device's teardown)
-        c.plan = plan;
-        c.device = dev;
-        c.q = modulus[0];
-        c.tw.assign(twiddles, twiddles + n);
-        c.pre.assign(precons, precons + n);
+    try {
+        if (dev < 0 || dev >= kPoolDevices) {      // no cache slot: build, use, destroy
+            agx_ntt_plan* plan = nullptr;
+            if ((rc = build_plan(&plan, n, 1, modulus, nullptr, twiddles, precons, nullptr, nullptr))) return rc;
+            rc = agx_ntt_forward_host_stream(plan, in, in2, out, num_frames);
+            free_plan(plan);
+            return rc;
+        }
+        oneshot_cache& c = g_oneshot[dev];
+        std::lock_guard<std::mutex> lock(c.mu);    // one-shot calls are synchronous; those of one device also serialise
+        const bool hit = c.plan && c.plan->n == n && c.q == modulus[0] &&
+                         std::memcmp(c.tw.data(), twiddles, (size_t)n * 8) == 0 && std::memcmp(c.pre.data(), precons, (size_t)n * 8) == 0;
+        if (!hit) {
+            agx_ntt_plan* plan = nullptr;
+            if ((rc = build_plan(&plan, n, 1, modulus, nullptr, twiddles, precons, nullptr, nullptr))) return rc;
+            free_plan(c.plan);
+            c.plan = plan;
+            c.q = modulus[0];
+            c.tw.assign(twiddles, twiddles + n);
+            c.pre.assign(precons, precons + n);
+        }
+        return agx_ntt_forward_host_stream(c.plan, in, in2, out, num_frames);
+    } catch (const std::bad_alloc&) {
+        return AGX_ERR_ALLOC;
+    } catch (...) {
+        return AGX_ERR_BAD_ARGUMENT;
     }
-    return agx_ntt_forward_host_stream(c.plan, in, in2, out, num_frames);
+}
+
+// Frees what the library keeps between calls: the one-shot plans and the pinned / device staging buffers of every device
+// (192 MiB pinned + 96 MiB device memory per device that has streamed host frames).  Call it before hipDeviceReset or at
+// shutdown; calls running at the same time keep what they hold (a busy staging set is skipped).  Later calls rebuild on demand.
+int agx_ntt_release_caches(void) {
+    for (int d = 0; d < kPoolDevices; ++d) {
+        {
+            std::lock_guard<std::mutex> lock(g_oneshot[d].mu);
+            if (g_oneshot[d].plan) {
+                free_plan(g_oneshot[d].plan);
+                g_oneshot[d].plan = nullptr;
+                g_oneshot[d].tw.clear();
+                g_oneshot[d].pre.clear();
+            }
+        }
+        if (g_stage_mu[d].try_lock()) {
+            if (g_stage_pool[d].bytes) {
+                int cur = -1;
+                if (hipGetDevice(&cur) == hipSuccess && hipSetDevice(d) == hipSuccess) {
+                    g_stage_pool[d].destroy();
+                    (void)hipSetDevice(cur);
+                }
+            }
+            g_stage_mu[d].unlock();
+        }
+    }
+    return AGX_OK;
 }
 
 int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t* primes_out) {
@@ -709,10 +796,12 @@ int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t* pri
     int rc = check_size(n);
     if (rc) return rc;
     if (bits < 2 || bits > 62) return AGX_ERR_BAD_ARGUMENT;
-    std::vector<uint64_t> v = find_ntt_primes(bits, n, count);
-    if (v.size() < count) return AGX_ERR_BAD_ARGUMENT;
-    std::memcpy(primes_out, v.data(), sizeof(uint64_t) * count);
-    return AGX_OK;
+    return guarded([&]() -> int {
+        std::vector<uint64_t> v = find_ntt_primes(bits, n, count);
+        if (v.size() < count) return AGX_ERR_BAD_ARGUMENT;
+        std::memcpy(primes_out, v.data(), sizeof(uint64_t) * count);
+        return AGX_OK;
+    });
 }
 
 int agx_ntt_min_root(uint64_t q, uint32_t n, uint64_t* psi_out) {

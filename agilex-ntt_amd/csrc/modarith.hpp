@@ -318,10 +318,11 @@ __device__ __forceinline__ uint64_t reduce_final_lazy16(uint64_t v, const bf_con
 // the estimate k' is floor(v/q) or one less (never above: the remainder stays non-negative) -- then v - k' q in [0,2q)
 // and one conditional subtract finishes: 3 conversions/multiplies + 2 integer multiplies + 1 subtract step instead of
 // four subtract steps.  Smaller moduli (top word too short for the estimate) take the four steps.
-template <bool SEL>
+// USE_EST: 1 = the caller has checked k.est_inv != 0 (quotient estimate), 0 = it has checked it is 0 (four steps), -1 = decide here
+template <bool SEL, int USE_EST = -1>
 __device__ __forceinline__ uint64_t reduce_final_est(uint64_t v, const bf_consts& k, const final_consts& f, bool lazy_out) {
     static_assert(SEL, "select-based conditional subtract only");
-    if (k.est_inv != 0.0f) {   // wave-uniform
+    if (USE_EST == 1 || (USE_EST == -1 && k.est_inv != 0.0f)) {   // wave-uniform
         const uint32_t kq = (uint32_t)((float)(uint32_t)(v >> 32) * k.est_inv);
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         u32x2 r = __builtin_bit_cast(u32x2, mad64(kq, (uint32_t)k.nq, v));      // v + k' * (2^64 - q), low word of -q

@@ -218,7 +218,7 @@ namespace {
 template <class F>
 void for_each_entry(F&& f) {
     const rb_span groups[] = {rb_entries_n4096(), rb_entries_n4096_ab(), rb_entries_n1024(), rb_entries_n2048(), rb_entries_n8192(),
-                              rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_gen1(),
+                              rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_r5(), rb_entries_gen1(),
 #ifdef AGX_DIAG
                               rb_entries_diag(),
 #endif
@@ -255,6 +255,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
     // an entry serves n if its resident size plus its (fixed or default) number of split stages is log_n
     auto split_for = [&](const rb_entry& e) -> int {
         if (e.fused_split > 0) return e.log_local + e.fused_split == log_n ? e.fused_split : -1;
+        if (e.log_local == log_n) return 0;      // whole frame resident (n = 32768: split-word image)
         const int split = log_n > kMaxLdsLog ? log_n - kMaxLdsLog : 0;
         return e.log_local + split == log_n ? split : -1;
     };

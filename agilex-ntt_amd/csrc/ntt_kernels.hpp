@@ -35,7 +35,12 @@ struct plan_view {
     regblock_layout rb;                    // forward register-blocked layout
     const ulonglong2* tw_rb = nullptr;     // [P][rb.pairs_per_prime]
     const ulonglong2* itw_rb = nullptr;    // same layout from the inverse tables, or null
-    uint32_t* ticket = nullptr;            // streaming kernel only: this plan's {frame ticket, retired workgroups} pair
+    // Kernels that hand out frames through a counter ask for a {next frame, retired workgroups} pair of the plan HERE, at launch time and
+    // only if they need one: the pair is keyed by the stream (launches on one stream serialise, so they may share a pair; the last
+    // workgroup out zeroes it).  nullptr = no pair can be proven free (too many distinct streams): take the stateless fixed-stride form.
+    uint32_t* (*ticket_for)(void* ctx, hipStream_t s) = nullptr;
+    void* ticket_ctx = nullptr;
+    uint32_t* ticket(hipStream_t s) const { return ticket_for ? ticket_for(ticket_ctx, s) : nullptr; }
 };
 
 struct frame_layout {

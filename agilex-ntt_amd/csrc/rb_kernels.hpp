@@ -240,6 +240,19 @@ constexpr int kOptEstReduce = 524288;   // with kOptLazy16: tail-free subtract s
 constexpr int kOptSplitWord = 1048576;  // forward only: exchanges move the low and the high 32-bit words in turn through an image of HALF
                                         // the size (4n bytes) -- the LDS footprint that lets R = 4 workgroups of 4 waves fill a CU (VERDICT r01 #1 ii)
 constexpr int kOptMulLoCross = 2097152; // 16q-lazy forward butterflies: the four cross products as 32-bit v_mul_lo_u32 (energy A/B, tools/microbench pwr)
+constexpr int kOptInvTwFirst = 4;       // inverse: the first (per-lane) pass's first-stage twiddles are requested right behind the frame loads, ahead of the
+                                        // LDS staging of the frame (otherwise their L2 latency starts only after the HBM latency of the frame has been paid)
+constexpr int kOptInvTwFirstAll = 8;    // with kOptInvTwFirst: every entry of that pass, not only its first stage's
+constexpr int kOptInvPrioTail = 1 << 22;   // inverse A/B: s_setprio 3 from the cross-wave exchange to the end (finish and free the slot)
+constexpr int kOptInvPrioAsc = 1 << 23;    // inverse A/B: priority rises pass by pass (0,1,2,3)
+constexpr int kOptInvPrioDesc = 1 << 24;   // inverse A/B: priority falls pass by pass (3,2,1,0): the workgroup's laggards catch up before the barrier
+constexpr int kOptStreamTw = 1 << 25;      // twiddles streamed in chunks of four table entries, one chunk requested ahead of the one in use, scheduling fenced per chunk:
+                                           // bounds the registers a pass's table entries occupy (R = 5: 31 entries per pass would be 124 SGPRs / VGPRs if fetched up front)
+constexpr int kOptPinBf = 1 << 26;         // with kOptStreamTw: butterflies are pinned in program order (their operands pass through ordered empty asm statements), so the
+                                           // instruction selector cannot start the partial products of the whole stage at once -- what takes an R = 5 pass from ~205 VGPRs to
+                                           // the 128 a 1024-thread workgroup may use; one wave cannot issue faster than one VALU per ~8 clocks anyway (ILP buys nothing there)
+constexpr int kOptSaddrTw = 1 << 27;       // per-lane table entries addressed as wave-uniform base (SGPRs) + 32-bit lane index (always on with kOptStreamTw)
+constexpr int kOptFinalMode = 1 << 28;     // the last stage branches once per stage on the final-reduction mode instead of once per coefficient (always on with kOptStreamTw)
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
 // where the kOptTrace kernels write: [wave][16] words, set through agx_ntt_debug_set_trace_buffer
@@ -269,6 +282,9 @@ struct rb2_frame {
     static constexpr bool TWA_INV = (OPT & kOptTwAheadInv) != 0 && R == 3;
     static constexpr bool EST = LAZY16 && SEL && (OPT & kOptEstReduce) != 0;
     static constexpr bool SPLIT = (OPT & kOptSplitWord) != 0;
+    static constexpr bool STREAM_TW = (OPT & kOptStreamTw) != 0;
+    static constexpr bool SADDR_TW = STREAM_TW || (OPT & kOptSaddrTw) != 0, FINAL_MODE = STREAM_TW || (OPT & kOptFinalMode) != 0;
+    static constexpr bool INV_TWF = (OPT & kOptInvTwFirst) != 0 && G::rlo(NP - 1) < 6, INV_TWF_ALL = INV_TWF && (OPT & kOptInvTwFirstAll) != 0;
     static_assert(!SPLIT || PAD, "the split-word image uses the padded index");
     static_assert(!EST || lazy16_tailfree::valid(S0 + L), "tail-free schedule must keep every stage within 16q");
     mutable uint64_t ts[12];
@@ -299,6 +315,7 @@ struct rb2_frame {
     // a per-lane pass with all R stages: the shape the look-ahead twiddle fetch handles
     static constexpr bool lane_full_pass(int p) { return p >= 0 && p < NP && G::rlo(p) < 6 && G::hi(p) - G::rlo(p) + 1 == R; }
     static constexpr uint32_t slab_elems = PAD ? (1u << L) + (1u << (L - 4)) : (1u << L);
+    static constexpr uint32_t image_bytes = slab_elems * (((OPT & kOptSplitWord) != 0) ? 4u : 8u);   // one frame's LDS image
     // image word of coefficient e; both forms are additive over disjoint bit fields, which is what
     // lets an exchange address register r as (thread base) combined with a compile-time constant
     static __device__ __forceinline__ constexpr uint32_t img(uint32_t e) { return PAD ? e + (e >> 4) : lds_swz(e); }
@@ -334,6 +351,41 @@ struct rb2_frame {
         else ct_butterfly_exact(a, b, w.x, w.y, k);
     }
 
+    // final reduction of one coefficient.  MODE bit 0: lazy outputs; bit 1: quotient estimate (EST kernels, q >= 2^58).  The caller branches ONCE per group of butterflies on the wave-uniform conditions (lazy_out, est_inv) and
+    // passes the outcome here as a constant, so the last stage is straight-line code (a branch per coefficient splits it into dozens of
+    // basic blocks, which costs registers: R = 5 kernels went from 204 to the VGPRs of the arithmetic proper).
+    template <int MODE>
+    __device__ __forceinline__ uint64_t final_reduce(uint64_t v) const {
+        if constexpr (MODE == 4) {      // undecided: branch per coefficient (the old form)
+            if constexpr (EST) return reduce_final_est<SEL>(v, k, fc, lazy_out);
+            else if constexpr (LAZY16) return reduce_final_lazy16<SEL>(v, k, fc, lazy_out);
+            else return reduce_final<FAST, SEL>(v, k, fc, lazy_out);
+        }
+        if constexpr (EST) return reduce_final_est<SEL, (MODE & 2) ? 1 : 0>(v, k, fc, (MODE & 1) != 0);
+        else if constexpr (LAZY16) return reduce_final_lazy16<SEL>(v, k, fc, (MODE & 1) != 0);
+        else return reduce_final<FAST, SEL>(v, k, fc, (MODE & 1) != 0);
+    }
+    // run body(integral_constant<int, MODE>) under the wave-uniform choice of the final-reduction mode
+    template <class Body>
+    __device__ __forceinline__ void with_final_mode(Body&& body) const {
+        if constexpr (!FINAL_MODE) {
+            body(std::integral_constant<int, 4>{});      // the kernels tuned at the 64-VGPR edge keep the per-coefficient form
+            return;
+        }
+        if (lazy_out) {
+            // EST kernels: lazy outputs of q >= 2^58 still take the estimate (MODE 1 inside reduce_final_est keys on est_inv itself)
+            if constexpr (EST) {
+                if (k.est_inv != 0.0f) body(std::integral_constant<int, 3>{});
+                else body(std::integral_constant<int, 1>{});
+            } else body(std::integral_constant<int, 1>{});
+        } else {
+            if constexpr (EST) {
+                if (k.est_inv != 0.0f) body(std::integral_constant<int, 2>{});
+                else body(std::integral_constant<int, 0>{});
+            } else body(std::integral_constant<int, 0>{});
+        }
+    }
+
     // image word of (pass p, register r) for this thread
     template <int p>
     __device__ __forceinline__ uint32_t sbase() const {
@@ -355,19 +407,36 @@ struct rb2_frame {
         if constexpr (rlo >= 6) {
             const uint32_t hcol = (uint32_t)__builtin_amdgcn_readfirstlane((int)high);
             const twpair* ucol = tbl + G::table_off(p) * (1u << split_log) + ((size_t)blk * H + hcol) * C;
+            if constexpr (STREAM_TW) {
+                t.col = ucol;      // entries are read chunk by chunk (stream_load)
+            } else {
 #pragma unroll
-            for (int j = 1; j < C; ++j) t.tw[j] = load_uniform(ucol + j);      // merged into wide s_loads
-            t.col = nullptr;
+                for (int j = 1; j < C; ++j) t.tw[j] = load_uniform(ucol + j);      // merged into wide s_loads
+                t.col = nullptr;
+            }
             t.hstride = 0;
         } else {
-            t.col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + ((OPT & kOptAblateTw) ? 0u : high);
+            t.col = tbl;
             t.hstride = (uint32_t)H << split_log;
         }
+    }
+    // Entry j of per-lane pass p's table for this lane, addressed as (wave-uniform base of the entry, in SGPRs) + (32-bit lane index):
+    // the load takes the saddr form and no entry needs a 64-bit VGPR address of its own (R = 5: 31 entries per pass would be 62 VGPRs).
+    template <int p>
+    __device__ __forceinline__ twpair lane_entry(const twpair* tbl, int j) const {
+        constexpr int rlo = G::rlo(p), H = G::H(p);
+        if constexpr (!SADDR_TW) {
+            const twpair* col = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + ((OPT & kOptAblateTw) ? 0u : (tid >> rlo));
+            return col[(size_t)j * ((uint32_t)H << split_log)];
+        }
+        const twpair* base = tbl + G::table_off(p) * (1u << split_log) + (size_t)blk * H + (size_t)j * ((uint32_t)H << split_log);
+        const uint32_t lane = (OPT & kOptAblateTw) ? 0u : (tid >> rlo);
+        return base[lane];
     }
     template <int p>
     __device__ __forceinline__ twpair twiddle(const tw_src<p>& t, int j) const {
         if constexpr (G::rlo(p) >= 6) return t.tw[j];
-        else return t.col[(size_t)j * t.hstride];
+        else return lane_entry<p>(t.col, j);
     }
 
     template <int p>
@@ -414,8 +483,84 @@ struct rb2_frame {
         rb2_no_hooks none;
         forward_passes<P0, P1>(x, tbl, none);
     }
+    // ---- streamed twiddles (STREAM_TW) -------------------------------------------------------------------------------
+    // A pass of ns stages reads, at its stage S, the 2^kk table entries j = 2^kk + o (kk = R - ns + S, o = b >> rb for butterfly b):
+    // they are taken in chunks of up to CH entries, in stage order; chunk q+1 is requested before chunk q's butterflies run.
+    static constexpr int CH = R >= 5 ? 2 : 4;      // R = 5: two entries (8 VGPRs per buffer) keep the pass inside 128 VGPRs
+    // forward: stage S of a pass has kk = R - ns + S (1, 2, 4 ... entries); inverse (INV): stages run the other way, kk = R - 1 - S
+    static constexpr int st_kk(int ns, int S, bool inv = false) { return inv ? R - 1 - S : R - ns + S; }
+    static constexpr int st_chunks_in_stage(int ns, int S, bool inv = false) { return (1 << st_kk(ns, S, inv)) > CH ? (1 << st_kk(ns, S, inv)) / CH : 1; }
+    static constexpr int st_total(int ns, bool inv = false) { int t = 0; for (int S = 0; S < ns; ++S) t += st_chunks_in_stage(ns, S, inv); return t; }
+    static constexpr int st_stage(int ns, int q, bool inv = false) { int S = 0; while (q >= st_chunks_in_stage(ns, S, inv)) { q -= st_chunks_in_stage(ns, S, inv); ++S; } return S; }
+    static constexpr int st_chunk(int ns, int q, bool inv = false) { int S = 0; while (q >= st_chunks_in_stage(ns, S, inv)) { q -= st_chunks_in_stage(ns, S, inv); ++S; } return q; }
+    static constexpr int st_count(int ns, int S, bool inv = false) { return (1 << st_kk(ns, S, inv)) < CH ? (1 << st_kk(ns, S, inv)) : CH; }
+    struct tw_chunk {
+        twpair e[CH];
+    };
+    template <int p, int q, bool INV = false>
+    __device__ __forceinline__ void stream_load(tw_chunk& c, const tw_src<p>& t) const {
+        constexpr int ns = G::hi(p) - G::rlo(p) + 1, S = st_stage(ns, q, INV), cc = st_chunk(ns, q, INV), kk = st_kk(ns, S, INV);
+        static_for<0, st_count(ns, S, INV)>([&](auto I) {
+            constexpr int j = (1 << kk) + cc * CH + (int)I;
+            if constexpr (G::rlo(p) >= 6) c.e[I] = load_uniform(t.col + j);
+            else c.e[I] = lane_entry<p>(t.col, j);
+        });
+    }
+    template <int P0, int P1, class Hooks>
+    __device__ __forceinline__ void forward_passes_streamed(uint64_t (&x)[C], const twpair* tbl, Hooks& hooks) const {
+        static_assert(P0 == 0 && P1 == NP, "whole transform");
+        static_for<P0, P1>([&](auto P) {
+            constexpr int p = P;
+            constexpr int rlo = G::rlo(p), hi = G::hi(p), ns = hi - rlo + 1, NQ = st_total(ns);
+            tw_src<p> t;
+            fetch<p>(t, tbl);
+            tw_chunk buf[2];
+            stream_load<p, 0>(buf[0], t);
+            if constexpr (p > 0 && !SPLIT) image_read<p>(x);
+            static_for<0, NQ>([&](auto Qc) {
+                constexpr int q = Qc;
+                constexpr int S = st_stage(ns, q), cc = st_chunk(ns, q), cnt = st_count(ns, S);
+                constexpr int rb = (hi - rlo) - S;
+                constexpr bool last_stage = (rlo + rb) == 0;
+                if constexpr (q + 1 < NQ) stream_load<p, q + 1>(buf[(q + 1) & 1], t);
+                __builtin_amdgcn_sched_barrier(0);
+                auto chunk_body = [&](auto M) {
+                    static_for<(cc * CH) << rb, (cc * CH + cnt) << rb>([&](auto B) {
+                        constexpr int b = B;
+                        constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
+                        constexpr int r1 = r0 | (1 << rb);
+                        constexpr int stage = S0 + L - 1 - (rlo + rb);
+                        if constexpr ((OPT & kOptPinBf) != 0) asm volatile("" : "+v"(x[r0]), "+v"(x[r1]));
+                        butterfly<stage>(x[r0], x[r1], buf[q & 1].e[(b >> rb) - cc * CH]);
+                        if constexpr (last_stage) {
+                            x[r0] = final_reduce<decltype(M)::value>(x[r0]);
+                            x[r1] = final_reduce<decltype(M)::value>(x[r1]);
+                        }
+                        if constexpr ((OPT & kOptPinBf) != 0) asm volatile("" : "+v"(x[r0]), "+v"(x[r1]));
+                    });
+                };
+                if constexpr (last_stage) with_final_mode(chunk_body);
+                else chunk_body(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (p < NP - 1) {
+                hooks.template before_image_write<p>();
+                if constexpr (SPLIT) split_exchange<p>(x);
+                else {
+                    image_write<p>(x);
+                    exchange_sync<p>();
+                }
+                hooks.template after_exchange_sync<p>();
+            }
+        });
+    }
+
     template <int P0, int P1, class Hooks>
     __device__ __forceinline__ void forward_passes(uint64_t (&x)[C], const twpair* tbl, Hooks& hooks) const {
+        if constexpr (STREAM_TW) {
+            forward_passes_streamed<P0, P1>(x, tbl, hooks);
+            return;
+        }
         // look-ahead twiddles (TWA): entries 1..C/2-1 of the next per-lane pass are requested during the
         // last stage of the current pass, entries C/2..C-1 at the start of their own pass, so the L2
         // latency of the per-lane table reads overlaps butterflies instead of stalling the wave
@@ -431,9 +576,9 @@ struct rb2_frame {
             twpair late[C / 2];   // entries C/2 .. C-1 (the pass's last stage)
             if constexpr (twa_here) {
                 if constexpr (!twa_prev) {
-                    static_for<1, C / 2>([&](auto J) { constexpr int j = J; ahead[j] = t.col[(size_t)j * t.hstride]; });
+                    static_for<1, C / 2>([&](auto J) { constexpr int j = J; ahead[j] = lane_entry<p>(tbl, j); });
                 }
-                static_for<0, C / 2>([&](auto J) { constexpr int j = J; late[j] = t.col[(size_t)(j + C / 2) * t.hstride]; });
+                static_for<0, C / 2>([&](auto J) { constexpr int j = J; late[j] = lane_entry<p>(tbl, j + C / 2); });
             }
             hooks.template after_twiddle_issue<p>();
             if constexpr (p > 0 && !SPLIT) {
@@ -448,36 +593,31 @@ struct rb2_frame {
                 if constexpr (twa_next && S == (ns > 1 ? ns - 1 : 0)) {
                     // `ahead` is free once this pass's first two stages are done
                     constexpr int pn = p + 1;
-                    const twpair* ncol = tbl + G::table_off(pn) * (1u << split_log) + (size_t)blk * G::H(pn) + ((OPT & kOptAblateTw) ? 0u : (tid >> G::rlo(pn)));
-                    const uint32_t nstride = (uint32_t)G::H(pn) << split_log;
-                    static_for<1, C / 2>([&](auto J) { constexpr int j = J; ahead[j] = ncol[(size_t)j * nstride]; });
+                    static_for<1, C / 2>([&](auto J) { constexpr int j = J; ahead[j] = lane_entry<pn>(tbl, j); });
                 }
-                static_for<0, C / 2>([&](auto B) {
-                    // B-th butterfly of the stage: insert a 0 at register bit rb
-                    constexpr int b = B;
-                    constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
-                    constexpr int r1 = r0 | (1 << rb);
-                    constexpr int j = (1 << kk) + (r0 >> (rb + 1));
-                    twpair w;
-                    if constexpr (twa_here && j < C / 2) w = ahead[j];
-                    else if constexpr (twa_here) w = late[j - C / 2];
-                    else w = twiddle<p>(t, j);
-                    constexpr int stage = S0 + L - 1 - (rlo + rb);   // position in the whole transform
-                    butterfly<stage>(x[r0], x[r1], w);
-                    if constexpr (last_stage) {
-                        if constexpr (EST) {
-                            x[r0] = reduce_final_est<SEL>(x[r0], k, fc, lazy_out);
-                            x[r1] = reduce_final_est<SEL>(x[r1], k, fc, lazy_out);
-                        } else if constexpr (LAZY16) {
-                            x[r0] = reduce_final_lazy16<SEL>(x[r0], k, fc, lazy_out);
-                            x[r1] = reduce_final_lazy16<SEL>(x[r1], k, fc, lazy_out);
-                        } else {
-                            x[r0] = reduce_final<FAST, SEL>(x[r0], k, fc, lazy_out);
-                            x[r1] = reduce_final<FAST, SEL>(x[r1], k, fc, lazy_out);
+                // the transform's last stage: one wave-uniform branch around the whole stage picks the final-reduction mode
+                auto stage_body = [&](auto M) {
+                    static_for<0, C / 2>([&](auto B) {
+                        // B-th butterfly of the stage: insert a 0 at register bit rb
+                        constexpr int b = B;
+                        constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
+                        constexpr int r1 = r0 | (1 << rb);
+                        constexpr int j = (1 << kk) + (r0 >> (rb + 1));
+                        twpair w;
+                        if constexpr (twa_here && j < C / 2) w = ahead[j];
+                        else if constexpr (twa_here) w = late[j - C / 2];
+                        else w = twiddle<p>(t, j);
+                        constexpr int stage = S0 + L - 1 - (rlo + rb);   // position in the whole transform
+                        butterfly<stage>(x[r0], x[r1], w);
+                        if constexpr (last_stage) {
+                            x[r0] = final_reduce<decltype(M)::value>(x[r0]);
+                            x[r1] = final_reduce<decltype(M)::value>(x[r1]);
                         }
-                    }
-                    hooks.template after_butterfly<p, S == ns - 1, b>();
-                });
+                        hooks.template after_butterfly<p, S == ns - 1, b>();
+                    });
+                };
+                if constexpr (last_stage) with_final_mode(stage_body);
+                else stage_body(std::integral_constant<int, 0>{});
             });
             if constexpr (2 * p + 2 < 12) stamp<2 * p + 2>(x[C - 1]);
             if constexpr (p < NP - 1) {
@@ -509,19 +649,126 @@ struct rb2_frame {
         forward_passes<0, NP>(x, tbl, hooks);
     }
 
+    // INV_TWF: twiddles of the inverse's first pass (the last pass's table, per lane) held in registers from before the
+    // frame has arrived; entry j serves stage rb = R-1-floor(log2 j) of that pass
+    struct inv_pre {
+        twpair tw[C];
+    };
+    static constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+    static constexpr bool inv_pre_has(int j) {
+        constexpr int p = NP - 1;
+        const int rb = R - 1 - ilog2(j);
+        return INV_TWF && rb <= G::hi(p) - G::rlo(p) && (INV_TWF_ALL || rb == 0);
+    }
+    __device__ __forceinline__ void inverse_prefetch(inv_pre& pre, const twpair* itbl) const {
+        if constexpr (INV_TWF) {
+            constexpr int p = NP - 1;
+            tw_src<p> t;
+            fetch<p>(t, itbl);
+            static_for<1, C>([&](auto J) {
+                constexpr int j = J;
+                if constexpr (inv_pre_has(j)) pre.tw[j] = lane_entry<p>(itbl, j);
+            });
+        }
+    }
+    __device__ __forceinline__ void inverse(uint64_t (&x)[C], const twpair* itbl, const prime_consts& pc) const {
+        inv_pre pre;
+        inverse_prefetch(pre, itbl);
+        inverse(x, itbl, pc, pre);
+    }
+
+    // SPLIT: the exchange between inverse passes p and p-1 through the 32-bit image (the mirror of split_exchange)
+    template <int p>
+    __device__ __forceinline__ void split_exchange_inv(uint64_t (&x)[C]) const {
+        uint32_t* w = reinterpret_cast<uint32_t*>(slab);
+        const uint32_t sb = sbase<p>(), nb = sbase<p - 1>();
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; w[join(sb, img((uint32_t)r << G::rlo(p)))] = (uint32_t)x[r]; });
+        exchange_sync<p - 1>();
+        uint32_t lo[C];
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; lo[r] = w[join(nb, img((uint32_t)r << G::rlo(p - 1)))]; });
+        exchange_sync<p - 1>();
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; w[join(sb, img((uint32_t)r << G::rlo(p)))] = (uint32_t)(x[r] >> 32); });
+        exchange_sync<p - 1>();
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; x[r] = (uint64_t)lo[r] | ((uint64_t)w[join(nb, img((uint32_t)r << G::rlo(p - 1)))] << 32); });
+    }
+
+    // STREAM_TW form of the inverse (whole frames only: split_log = 0, so the top stage folds n^-1 in): twiddles in chunks, one chunk
+    // ahead, butterflies pinned in program order (kOptPinBf) -- see forward_passes_streamed
+    __device__ __forceinline__ void inverse_streamed(uint64_t (&x)[C], const twpair* itbl, const prime_consts& pc) const {
+        static_for<0, NP>([&](auto Qp) {
+            constexpr int p = NP - 1 - Qp;
+            constexpr int rlo = G::rlo(p), hi = G::hi(p), ns = hi - rlo + 1, NQ = st_total(ns, true);
+            constexpr int B0 = (p == NP - 1) ? 4 : 8;
+            tw_src<p> t;
+            fetch<p>(t, itbl);
+            tw_chunk buf[2];
+            stream_load<p, 0, true>(buf[0], t);
+            if constexpr (p < NP - 1 && !SPLIT) image_read<p>(x);
+            static_for<0, NQ>([&](auto Qc) {
+                constexpr int q = Qc;
+                constexpr int S = st_stage(ns, q, true), cc = st_chunk(ns, q, true), cnt = st_count(ns, S, true);
+                constexpr int rb = S;                         // gap bits ascend
+                constexpr bool top_stage = (rlo + rb) == L - 1;
+                if constexpr (q + 1 < NQ) stream_load<p, q + 1, true>(buf[(q + 1) & 1], t);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<(cc * CH) << rb, (cc * CH + cnt) << rb>([&](auto Bf) {
+                    constexpr int b = Bf;
+                    constexpr int r0 = ((b >> rb) << (rb + 1)) | (b & ((1 << rb) - 1));
+                    constexpr int r1 = r0 | (1 << rb);
+                    constexpr int BND = gs_bound(B0, rb, r0);
+                    if constexpr ((OPT & kOptPinBf) != 0) asm volatile("" : "+v"(x[r0]), "+v"(x[r1]));
+                    if constexpr (top_stage) {
+                        if constexpr (LAZY_INV) gs_last_lazy16<BND, SEL>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k, fc);
+                        else gs_last_form<FAST>(x[r0], x[r1], pc.n_inv, pc.n_inv_p, pc.w1n, pc.w1n_p, k);
+                        x[r0] = reduce_final_inv<FAST, SEL>(x[r0], k, fc);
+                        x[r1] = reduce_final_inv<FAST, SEL>(x[r1], k, fc);
+                    } else {
+                        const twpair w = buf[q & 1].e[(b >> rb) - cc * CH];
+                        if constexpr (LAZY_INV) gs_butterfly_lazy16<BND, SEL>(x[r0], x[r1], w.x, w.y, k, fc);
+                        else gs_butterfly_form<FAST, SEL>(x[r0], x[r1], w.x, w.y, k);
+                    }
+                    if constexpr ((OPT & kOptPinBf) != 0) asm volatile("" : "+v"(x[r0]), "+v"(x[r1]));
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (LAZY_INV && p > 0) {
+                static_for<0, C>([&](auto Rr) {
+                    constexpr int r = Rr;
+                    if constexpr (gs_bound(B0, ns, r) == 16) x[r] = csub_8q<SEL>(x[r], fc);
+                });
+            }
+            if constexpr (p > 0) {
+                if constexpr (SPLIT) split_exchange_inv<p>(x);
+                else {
+                    image_write<p>(x);
+                    exchange_sync<p - 1>();
+                }
+            }
+        });
+    }
+
     // x in the last pass's layout, values in [0,m) -> inverse transform (Gentleman-Sande, gap bits
     // ascending), x in pass-0 layout, fully reduced.  With split_log = 0 the top stage also
     // multiplies by n^-1; otherwise inv_global_stage finishes the transform.
-    __device__ __forceinline__ void inverse(uint64_t (&x)[C], const twpair* itbl, const prime_consts& pc) const {
+    __device__ __forceinline__ void inverse(uint64_t (&x)[C], const twpair* itbl, const prime_consts& pc, const inv_pre& pre) const {
+        if constexpr (STREAM_TW) {
+            inverse_streamed(x, itbl, pc);
+            return;
+        }
         twpair first[4];     // TWA_INV: entries 4..7 of the pass about to start (its first stage), fetched one pass early
         static_for<0, NP>([&](auto Q) {
             constexpr int p = NP - 1 - Q;
             constexpr int rlo = G::rlo(p), hi = G::hi(p);
             constexpr bool twa_have = TWA_INV && p < NP - 1 && lane_full_pass(p) && lane_full_pass(p + 1);   // the previous pass fetched `first`
             constexpr bool twa_next = TWA_INV && p > 0 && lane_full_pass(p) && lane_full_pass(p - 1);
+            if constexpr ((OPT & kOptInvPrioAsc) != 0) __builtin_amdgcn_s_setprio(Q >= 3 ? 3 : (int)Q);
+            if constexpr ((OPT & kOptInvPrioDesc) != 0) __builtin_amdgcn_s_setprio(Q >= 3 ? 0 : 3 - (int)Q);
             tw_src<p> t;
             fetch<p>(t, itbl);
-            if constexpr (p < NP - 1) image_read<p>(x);
+            if constexpr (p < NP - 1) {
+                image_read<p>(x);
+                if constexpr (2 + 2 * Q < 12) stamp<2 + 2 * Q>(x[C - 1]);     // trace: exchange done (Q = passes completed)
+            }
             // 16q-lazy form: every register of the first pass starts below 4q, of the later ones below 8q
             constexpr int B0 = (p == NP - 1) ? 4 : 8;
             static_for<0, hi - rlo + 1>([&](auto S) {
@@ -531,9 +778,7 @@ struct rb2_frame {
                 if constexpr (twa_next && S == hi - rlo) {
                     // `first` is free: this pass's first stage is long done
                     constexpr int pn = p - 1;
-                    const twpair* ncol = itbl + G::table_off(pn) * (1u << split_log) + (size_t)blk * G::H(pn) + (tid >> G::rlo(pn));
-                    const uint32_t nstride = (uint32_t)G::H(pn) << split_log;
-                    static_for<0, 4>([&](auto J) { constexpr int jj = J; first[jj] = ncol[(size_t)(jj + 4) * nstride]; });
+                    static_for<0, 4>([&](auto J) { constexpr int jj = J; first[jj] = lane_entry<pn>(itbl, jj + 4); });
                 }
                 static_for<0, C / 2>([&](auto Bf) {
                     constexpr int b = Bf;
@@ -547,6 +792,7 @@ struct rb2_frame {
                         constexpr int j = (1 << kk) + (r0 >> (rb + 1));
                         twpair w;
                         if constexpr (twa_have && j >= 4) w = first[j - 4];
+                        else if constexpr (p == NP - 1 && inv_pre_has(j)) w = pre.tw[j];
                         else w = twiddle<p>(t, j);
                         if constexpr (LAZY_INV) {
                             gs_butterfly_lazy16<BND, SEL>(x[r0], x[r1], w.x, w.y, k, fc);
@@ -564,6 +810,7 @@ struct rb2_frame {
                     }
                 });
             });
+            if constexpr (3 + 2 * Q < 12) stamp<3 + 2 * Q>(x[C - 1]);       // trace: this pass's butterflies done
             if constexpr (LAZY_INV && p > 0) {
                 // the next pass assumes 8q: bring the registers that ended at 16q back
                 static_for<0, C>([&](auto Rr) {
@@ -572,6 +819,7 @@ struct rb2_frame {
                 });
             }
             if constexpr (p > 0) {
+                if constexpr ((OPT & kOptInvPrioTail) != 0 && !G::exchange_is_wave_local(p - 1)) __builtin_amdgcn_s_setprio(3);
                 image_write<p>(x);
                 exchange_sync<p - 1>();
             }
@@ -646,6 +894,31 @@ struct rb2_frame {
     // second half: optional coefficient-wise product with in2, staging through the wave's own part of the image
     __device__ __forceinline__ void load_last_stage(uint64_t (&x)[C], const uint64_t* __restrict__ in2, const barrett128& bk, int64_t base) const {
         const uint32_t e0 = ((tid >> 6) << (6 + R)) + (tid & 63u), s0 = img(e0);
+        if constexpr (SPLIT) {
+            // 32-bit image: low words through the wave's part of the image, then the high words
+            uint32_t* w = reinterpret_cast<uint32_t*>(slab);
+            const uint32_t own32 = img(tid << R);
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                uint64_t v = x[r];
+                if (in2) {   // wave-uniform
+                    const uint64_t u = (OPT & kOptNtLoad) ? __builtin_nontemporal_load(&in2[base + e0 + 64u * (uint32_t)r]) : in2[base + e0 + 64u * (uint32_t)r];
+                    v = mul_mod_barrett(reduce_4q(v, k.q, k.q << 1), reduce_4q(u, k.q, k.q << 1), bk);
+                }
+                if constexpr (!FAST) v = csub(v, k.m);
+                x[r] = v;
+            }
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; w[join(s0, img(64u * (uint32_t)r))] = (uint32_t)x[r]; });
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            wave_lds_sync();
+            uint32_t lo[C];
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; lo[r] = w[join(own32, img((uint32_t)r))]; });
+            wave_lds_sync();
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; w[join(s0, img(64u * (uint32_t)r))] = (uint32_t)(x[r] >> 32); });
+            wave_lds_sync();
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; x[r] = (uint64_t)lo[r] | ((uint64_t)w[join(own32, img((uint32_t)r))] << 32); });
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < C; ++r) {
             uint64_t v = x[r];
@@ -676,7 +949,7 @@ struct rb2_frame {
     if (!live) fx = frames_x - 1;                                                                 \
     const uint32_t prime = blockIdx.y;                                                            \
     const uint64_t poly = fx >> split_log;                                                        \
-    f.blk = (uint32_t)(fx & ((1u << split_log) - 1u));                                            \
+    f.blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(fx & ((1u << split_log) - 1u)));   /* wave-uniform (T >= 64) */ \
     f.split_log = split_log;                                                                      \
     f.init_consts(consts[prime].q, consts[prime].est);                                                               \
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds) + (size_t)slot * F::slab_elems;             \
@@ -795,7 +1068,7 @@ fwd_rb2_stream(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     f.split_log = 0;
     f.lazy_out = lazy_out != 0;
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
-    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(f.slab + F::slab_elems);   // two words behind the image
+    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<unsigned char*>(f.slab) + F::image_bytes);   // two words behind the image
 
 
     uint32_t fr = blockIdx.x;
@@ -940,7 +1213,7 @@ fwd_rb2_dloop(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
     f.split_log = 0;
     f.lazy_out = lazy_out != 0;
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
-    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(f.slab + F::slab_elems);   // two words behind the image
+    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<unsigned char*>(f.slab) + F::image_bytes);   // two words behind the image
     rb2_dloop_hooks hooks{true, mailbox, 0, 0};
     uint32_t fr = blockIdx.x;       // launch guarantees gridDim.x <= total
     for (uint32_t it = 0;; ++it) {
@@ -976,7 +1249,7 @@ inv_rb2_dloop(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2,
     f.blk = 0;
     f.split_log = 0;
     f.slab = reinterpret_cast<uint64_t*>(agx_dyn_lds);
-    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(f.slab + F::slab_elems);
+    volatile uint32_t* mailbox = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<unsigned char*>(f.slab) + F::image_bytes);
     uint32_t fr = blockIdx.x;
     for (uint32_t it = 0;; ++it) {
         const uint32_t prime = fr / batch, poly = fr % batch;
@@ -1140,19 +1413,49 @@ inv_rb2(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint6
         const prime_consts* __restrict__ consts, const twpair* __restrict__ itw_rb,
         uint32_t pairs_per_prime, uint32_t split_log, uint64_t frames_x,
         int64_t prime_stride, int64_t poly_stride) {
+    uint64_t t_entry = 0;
+    if constexpr (((ARITH >> 1) & kOptTrace) != 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) : : "memory");
     if constexpr (((ARITH >> 1) & kOptPrio) != 0) __builtin_amdgcn_s_setprio(3);   // until the frame loads are out
     AGX_RB2_PROLOGUE;
     const prime_consts pc = consts[prime];
     const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
     uint64_t x[C];
-    f.load_last_layout(x, in, in2, bk, base);
-    f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);
+    typename F::inv_pre pre;
+    if constexpr (((ARITH >> 1) & kOptAblateHbm) != 0) {
+        // timing only (wrong results): frame 0 of the prime (L2-resident) instead of the workgroup's own frame, for the loads, the stores or both
+        const int64_t hot = (int64_t)prime * prime_stride;
+        f.load_last_issue(x, in, (((ARITH >> 1) & kOptAblateStOnly) != 0) ? base : hot);
+        f.inverse_prefetch(pre, itw_rb + (size_t)prime * pairs_per_prime);
+        f.load_last_stage(x, in2, bk, base);
+        f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc, pre);
+        const int64_t ob = (((ARITH >> 1) & kOptAblateLdOnly) != 0) ? base : hot;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) out[ob + f.tid + (uint32_t)r * T] = x[r];
+        }
+        return;
+    }
+    f.load_last_issue(x, in, base);
+    f.inverse_prefetch(pre, itw_rb + (size_t)prime * pairs_per_prime);      // behind the frame loads, ahead of their wait
+    if constexpr (F::TRACE) {
+        f.ts[0] = t_entry;
+        f.template stamp<1>(x[C - 1]);      // frame arrived
+    }
+    f.load_last_stage(x, in2, bk, base);
+    if constexpr (F::TRACE) f.template stamp<2>(x[C - 1]);      // staged through the image into the last pass's layout
+    f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc, pre);
     if (live) {
 #pragma unroll
         for (int r = 0; r < C; ++r) {
             if constexpr (((ARITH >> 1) & kOptNtStore) != 0) __builtin_nontemporal_store(x[r], &out[base + f.tid + (uint32_t)r * T]);
             else out[base + f.tid + (uint32_t)r * T] = x[r];
         }
+    }
+    if constexpr (F::TRACE) {
+        f.template stamp<10>(x[0]);         // stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f.template stamp<11>(x[0]);         // stores retired
+        f.trace_flush();
     }
 }
 
@@ -1266,6 +1569,50 @@ polymul_rb2_park(const uint64_t* __restrict__ first, const uint64_t* __restrict_
 #pragma unroll
     for (int r = 0; r < C; ++r) x[r] = NTL ? __builtin_nontemporal_load(&first[base + f.tid + (uint32_t)r * T]) : first[base + f.tid + (uint32_t)r * T];
     f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
+    if constexpr (F::STREAM_TW) {
+        // Thread-private parking: every thread stores its own 2^R values of NTT(first) (register r at c[base + tid + r T]: lane-contiguous,
+        // not the natural element order -- c's frame is only scratch here) and later reads back exactly the words it wrote, one
+        // register at a time, so the product needs neither an LDS redistribution nor a second frame in registers.
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) c[base + f.tid + (uint32_t)r * T] = x[r];
+        }
+        asm volatile("" ::: "memory");      // the second operand's loads stay behind the parking stores (or two frames would be live)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < C; ++r) x[r] = NTL ? __builtin_nontemporal_load(&second[base + f.tid + (uint32_t)r * T]) : second[base + f.tid + (uint32_t)r * T];
+        __syncthreads();   // the image is reused
+        {
+            const twpair* tbl2 = tw_rb + (size_t)prime * pairs_per_prime;
+            asm volatile("" : "+s"(tbl2));      // opaque: or the first transform's table entries are kept (spilled) for reuse instead of re-read from L2
+            f.forward(x, tbl2);
+        }
+        const uint64_t* parked = c;
+        asm volatile("" : "+s"(parked));      // opaque: the compiler must re-load the parked words, not keep them in registers
+        constexpr int GRP = 4;
+        static_for<0, C / GRP>([&](auto Gq) {
+            constexpr int g = Gq;
+            uint64_t z[GRP];
+            static_for<0, GRP>([&](auto I) { constexpr int r = g * GRP + (int)I; z[I] = parked[base + f.tid + (uint32_t)r * T]; });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, GRP>([&](auto I) {
+                constexpr int r = g * GRP + (int)I;
+                asm volatile("" : "+v"(x[r]));
+                x[r] = mul_mod_barrett(z[I], x[r], bk);
+                asm volatile("" : "+v"(x[r]));
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                if constexpr (NTS) __builtin_nontemporal_store(x[r], &c[base + f.tid + (uint32_t)r * T]);
+                else c[base + f.tid + (uint32_t)r * T] = x[r];
+            }
+        }
+        return;
+    }
     f.store_last_layout(x, c, base, live);     // parked (coalesced, through the image)
 #pragma unroll
     for (int r = 0; r < C; ++r) x[r] = NTL ? __builtin_nontemporal_load(&second[base + f.tid + (uint32_t)r * T]) : second[base + f.tid + (uint32_t)r * T];
@@ -1434,12 +1781,13 @@ hipError_t launch_rb2_stream_t(const plan_view& pv, const uint64_t* in, uint64_t
     if (de != hipSuccess) return de;
     const int resident = cus * (MINW * 256 / G::T);   // workgroups the current device holds at MINW waves per SIMD
     const uint64_t total = fl.batch * pv.num_primes;
-    if (total >= (1ull << 31) || !pv.ticket) return hipErrorInvalidValue;
+    uint32_t* ticket = pv.ticket(s);
+    if (total >= (1ull << 31) || !ticket) return hipErrorInvalidValue;
     const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
     const unsigned grid = (unsigned)(total < (uint64_t)resident ? total : (uint64_t)resident);
     hipLaunchKernelGGL((fwd_rb2_stream<L, R, ARITH, MINW, PF>), dim3(grid), dim3(G::T), lds, s, in, out, pv.consts, pv.tw_rb,
                        pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride,
-                       (uint32_t)(fl.lazy_out ? 1 : 0), pv.ticket);
+                       (uint32_t)(fl.lazy_out ? 1 : 0), ticket);
     return hipGetLastError();
 }
 
@@ -1581,15 +1929,17 @@ template <int L, int R, int ARITH, int MINW>
 hipError_t launch_rb2_dloop_t(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     if (stream_is_capturing(s)) return launch_rb2_loop_t<L, R, ARITH, MINW>(pv, in, out, fl, s);
+    uint32_t* ticket = pv.ticket(s);
+    if (!ticket) return launch_rb2_loop_t<L, R, ARITH, MINW>(pv, in, out, fl, s);      // no pair provably free: stateless form
     unsigned resident = 0;
     hipError_t e = resident_workgroups<L, R, MINW>(&resident);
     if (e != hipSuccess) return e;
     const uint64_t total = fl.batch * pv.num_primes;
-    if (total >= (1ull << 31) || !pv.ticket) return hipErrorInvalidValue;
+    if (total >= (1ull << 31)) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(total < resident ? total : resident);
     const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
     hipLaunchKernelGGL((fwd_rb2_dloop<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, out, pv.consts, pv.tw_rb,
-                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride, (uint32_t)(fl.lazy_out ? 1 : 0), pv.ticket);
+                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride, (uint32_t)(fl.lazy_out ? 1 : 0), ticket);
     return hipGetLastError();
 }
 
@@ -1597,15 +1947,17 @@ template <int L, int R, int ARITH, int MINW>
 hipError_t launch_inv_rb2_dloop_t(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     if (stream_is_capturing(s)) return launch_inv_rb2_loop_t<L, R, ARITH, MINW>(pv, in, in2, out, fl, s);
+    uint32_t* ticket = pv.ticket(s);
+    if (!ticket) return launch_inv_rb2_loop_t<L, R, ARITH, MINW>(pv, in, in2, out, fl, s);
     unsigned resident = 0;
     hipError_t e = resident_workgroups<L, R, MINW>(&resident);
     if (e != hipSuccess) return e;
     const uint64_t total = fl.batch * pv.num_primes;
-    if (total >= (1ull << 31) || !pv.ticket) return hipErrorInvalidValue;
+    if (total >= (1ull << 31)) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(total < resident ? total : resident);
     const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
     hipLaunchKernelGGL((inv_rb2_dloop<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, in2, out, pv.consts, pv.itw_rb,
-                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride, pv.ticket);
+                       pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride, ticket);
     return hipGetLastError();
 }
 
@@ -1637,6 +1989,47 @@ constexpr rb_entry make_entry_dloop(int id) {
         e.launch_mul = &launch_mul_park_t<L, R, ARITH, MINW>;
         e.mul_parked = true;
     }
+    return e;
+}
+
+// whole-frame kernels with one frame in registers per workgroup at any time (R = 5: a second frame cannot be held):
+// forward, inverse, and the fused product by polymul_rb2_park; polymul_rb2 (two frames in registers) is not instantiated
+template <int L, int R, int ARITH, int MINW>
+hipError_t init_rb2_single_t() {
+    const int bytes = (int)rb2_lds_bytes<L, R, 1, ARITH>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2<L, R, 1, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2<L, R, 1, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = init_mul_park_t<L, R, ARITH, MINW>();
+    return e;
+}
+template <int L, int R, int ARITH, int MINW>
+constexpr rb_entry make_entry_single(int id) {
+    rb_entry e{id, L, R, 1, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, rb2_lds_bytes<L, R, 1, ARITH>(),
+               &build_table_t<L, R, true>, &launch_rb2_t<L, R, 1, ARITH, MINW>, &init_rb2_single_t<L, R, ARITH, MINW>,
+               (ARITH & 1) ? ((((ARITH >> 1) & kOptLazy16) != 0) ? 2 : 1) : 0,
+               &launch_inv_rb2_t<L, R, 1, ARITH, MINW>, &launch_mul_park_t<L, R, ARITH, MINW>, 0, nullptr, false};
+    e.mul_parked = true;
+    return e;
+}
+
+// ... with the forward (FWD) and / or inverse (INV) launches by the dynamic loop kernels (resident grid, ticket counter; captured
+// launches take the fixed-stride form)
+template <int L, int R, int ARITH, int MINW>
+hipError_t init_rb2_single_dloop_t() {
+    hipError_t e = init_rb2_single_t<L, R, ARITH, MINW>();
+    const int bytes = (int)rb2_lds_bytes<L, R, 1, ARITH>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_loop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2_loop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2_dloop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes + 16);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2_dloop<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes + 16);
+    return e;
+}
+template <int L, int R, int ARITH, int MINW, bool FWD, bool INV>
+constexpr rb_entry make_entry_single_dloop(int id) {
+    rb_entry e = make_entry_single<L, R, ARITH, MINW>(id);
+    e.init = &init_rb2_single_dloop_t<L, R, ARITH, MINW>;
+    if (FWD) e.launch = &launch_rb2_dloop_t<L, R, ARITH, MINW>;
+    if (INV) e.launch_inv_loop = &launch_inv_rb2_dloop_t<L, R, ARITH, MINW>;
     return e;
 }
 

@@ -47,6 +47,7 @@ rb_span rb_entries_n8192();
 rb_span rb_entries_n8192_split();
 rb_span rb_entries_n8192_pair();
 rb_span rb_entries_n16384();
+rb_span rb_entries_r5();
 #ifdef AGX_DIAG
 rb_span rb_entries_diag();                                      // trace twin, streaming A/B kernels, timing ablations
 hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves);   // where the trace kernels write

@@ -17,6 +17,16 @@ const rb_entry kEntries[] = {
     // against 0.274 for the default and 0.284 for id 66 (full image, 4 per CU); 7 / 8 per CU spill 64 / 100 B per lane: 0.317 / 0.351 ms
     make_entry_fwd_only<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptScalarBase | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptSplitWord) << 1), 6>(86),
     make_entry_fwd_only<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptScalarBase | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptSplitWord) << 1), 5>(89),
+    // A/B (inverse): 93 with the inverse's first-pass twiddles requested ahead of the frame's LDS staging (101: first stage's, 102: all seven)
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptInvTwFirst) << 1), 8>(101),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptInvTwFirst | kOptInvTwFirstAll) << 1), 8>(102),
+    // A/B (inverse): resident grid drawing frames from a ticket counter (the n = 16384 inverse's form) / fixed stride
+    make_entry_dloop<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8, false, true>(106),
+    make_entry_loop<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8, false>(107),
+    // A/B (inverse): priority policies
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptInvPrioTail) << 1), 8>(103),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptInvPrioAsc) << 1), 8>(104),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptInvPrioDesc) << 1), 8>(105),
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
 };

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- headline benchmark: batched n=4096 forward NTTs/s on N MI355X (BASELINE.json).
 
 A "step" is one forward pass of the hot path over one batch resident in HBM: per GPU,

@@ -24,6 +24,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#if defined(__GNUC__) || defined(__clang__)
+#define AGX_API __attribute__((visibility("default")))
+#else
+#define AGX_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -50,9 +57,9 @@ typedef enum agx_status {
 #define AGX_VARIANT_REGBLOCK 2   /* register-blocked radix-2^R passes, tuned configuration for n */
 #define AGX_VARIANT_REGBLOCK_BASE 256 /* + k: k-th entry of the kernel registry (A/B measurements only) */
 
-const char* agx_ntt_strerror(int status);
-int agx_ntt_last_hip_error(void);     /* hipError_t of the last AGX_ERR_HIP on this thread */
-int agx_ntt_device_count(int* count); /* AGX_OK and *count = 0 when there is no GPU */
+AGX_API const char* agx_ntt_strerror(int status);
+AGX_API int agx_ntt_last_hip_error(void);     /* hipError_t of the last AGX_ERR_HIP on this thread */
+AGX_API int agx_ntt_device_count(int* count); /* AGX_OK and *count = 0 when there is no GPU */
 
 /* ------------------------------------------------------------------------- */
 /* (1) One-shot host-pointer forward NTT.                                     */
@@ -66,7 +73,7 @@ int agx_ntt_device_count(int* count); /* AGX_OK and *count = 0 when there is no 
 /* runtime argument here (the reference fixes it at compile time,              */
 /* include/kernel/ntt.h:7-23).  Synchronous; all pointers are host memory.     */
 /* ------------------------------------------------------------------------- */
-int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
+AGX_API int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
                          const uint64_t* twiddles, const uint64_t* precons, uint64_t* out,
                          uint32_t n, uint32_t num_frames);
 
@@ -76,12 +83,21 @@ int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t
 /* src/kernel/ntt.cpp:508-640).  agx_ntt_forward_host is this call on a plan it builds from the caller's */
 /* tables and keeps for the next call with the same (n, modulus, tables).                              */
 struct agx_ntt_plan;
-int agx_ntt_forward_host_stream(const struct agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2,
+AGX_API int agx_ntt_forward_host_stream(const struct agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2,
                                 uint64_t* out, uint64_t num_frames);
+
+/* Releases what the library keeps between calls: the one-shot plan of every device (agx_ntt_forward_host keeps the plan of its */
+/* last call per device) and the per-device pool of pinned / device staging buffers of the streaming path (192 MiB pinned +     */
+/* 96 MiB device memory per device that has used it).  Call before hipDeviceReset and at shutdown; later calls rebuild on demand. */
+/* (The reference holds its buffers in SYCL RAII objects of main(), src/main.cpp:32-37; this is the explicit counterpart.)       */
+AGX_API int agx_ntt_release_caches(void);
 
 /* ------------------------------------------------------------------------- */
 /* (2) Plans: device-resident tables for num_primes moduli of one size n.      */
-/* A plan is immutable after creation and may be shared between host threads;  */
+/* A plan is immutable after creation and may be shared between host threads   */
+/* and streams (kernels that hand out frames through a counter keep one counter */
+/* pair per stream, for up to 64 distinct streams per plan; launches on further */
+/* streams take a stateless kernel form: slower by a few per cent, never wrong); */
 /* it belongs to the HIP device that was current when it was created: calls    */
 /* that take it return AGX_ERR_BAD_ARGUMENT while another device is current.   */
 /* ------------------------------------------------------------------------- */
@@ -90,17 +106,17 @@ typedef struct agx_ntt_plan agx_ntt_plan;
 /* caller-supplied tables, laid out [num_primes][n] (one reference launch per prime,
  * src/kernel/ntt.cpp:143-144,569).  inv_* may both be NULL (forward-only plan).
  * n_inv[p] = n^-1 mod q_p is derived internally. */
-int agx_ntt_plan_create(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, const uint64_t* moduli,
+AGX_API int agx_ntt_plan_create(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes, const uint64_t* moduli,
                         const uint64_t* twiddles, const uint64_t* precons,
                         const uint64_t* inv_twiddles, const uint64_t* inv_precons);
 
 /* tables generated by the library; psi == NULL -> smallest primitive 2n-th root per prime */
-int agx_ntt_plan_create_auto(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes,
+AGX_API int agx_ntt_plan_create_auto(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes,
                              const uint64_t* moduli, const uint64_t* psi);
-int agx_ntt_plan_destroy(agx_ntt_plan* plan);
-int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant); /* testing / benchmarking only */
-int agx_ntt_plan_info(const agx_ntt_plan* plan, uint32_t* n, uint32_t* num_primes, int* device, int* has_inverse);
-int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uint64_t* q, uint64_t* psi);
+AGX_API int agx_ntt_plan_destroy(agx_ntt_plan* plan);
+AGX_API int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant); /* testing / benchmarking only */
+AGX_API int agx_ntt_plan_info(const agx_ntt_plan* plan, uint32_t* n, uint32_t* num_primes, int* device, int* has_inverse);
+AGX_API int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uint64_t* q, uint64_t* psi);
 
 /* ------------------------------------------------------------------------- */
 /* (3) Device-pointer batched transforms.  Frame (p, b) starts at              */
@@ -111,30 +127,30 @@ int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uin
 /* captured into a hipGraph (kernels that hand out frames through a counter    */
 /* switch to a stateless form while the stream is capturing).                   */
 /* ------------------------------------------------------------------------- */
-int agx_ntt_forward(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
-int agx_ntt_inverse(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
+AGX_API int agx_ntt_forward(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
+AGX_API int agx_ntt_inverse(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
 /* forward with HEXL-style lazy outputs: results are congruent to the transform and lie in [0,4q)
  * (the last two conditional subtracts of src/kernel/ntt.cpp:377-394 are skipped where that saves
  * work); agx_ntt_inverse, agx_ntt_pointwise and agx_ntt_forward all accept such values as inputs */
-int agx_ntt_forward_lazy(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
-int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
+AGX_API int agx_ntt_forward_lazy(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch, void* stream);
+AGX_API int agx_ntt_forward_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
                             int64_t prime_stride, int64_t poly_stride, void* stream);
-int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
+AGX_API int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_in, uint64_t* d_out, uint64_t batch,
                             int64_t prime_stride, int64_t poly_stride, void* stream);
 
 /* c = a o b (coefficient-wise product mod q_p), dense [prime][batch][n] layout; c may alias a or b */
-int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
+AGX_API int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                       uint64_t batch, void* stream);
 /* c = a * b in Z_q[X]/(X^n + 1) = INTT(NTT(a) o NTT(b)); dense layout; c may alias a or b.
  * d_scratch: num_primes*batch*n elements of device memory owned by the caller, distinct from a, b, c.
  * It is only used when n has no one-launch fused kernel -- today n < 1024 and n >= 16384 -- and may be NULL
  * otherwise (1024 <= n <= 8192); a NULL scratch where one is needed returns AGX_ERR_NULL_POINTER. */
-int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
+AGX_API int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                     uint64_t* d_scratch, uint64_t batch, void* stream);
 
 /* synthetic coefficients generated on the device: frame (p,b) element i =
  * splitmix64(seed, p, first_poly + b, i) mod q_p, a pure function of its indices (bench / tests) */
-int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t batch, uint64_t first_poly,
+AGX_API int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t batch, uint64_t first_poly,
                            uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------- */
@@ -142,10 +158,10 @@ int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t b
 /* placeholders only).                                                          */
 /* ------------------------------------------------------------------------- */
 /* the `count` largest primes q < 2^bits with q = 1 (mod 2n), descending */
-int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t* primes_out);
-int agx_ntt_min_root(uint64_t q, uint32_t n, uint64_t* psi_out);
-int agx_ntt_make_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* twiddles, uint64_t* precons);
-int agx_ntt_make_inverse_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* inv_twiddles, uint64_t* inv_precons);
+AGX_API int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint64_t* primes_out);
+AGX_API int agx_ntt_min_root(uint64_t q, uint32_t n, uint64_t* psi_out);
+AGX_API int agx_ntt_make_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* twiddles, uint64_t* precons);
+AGX_API int agx_ntt_make_inverse_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* inv_twiddles, uint64_t* inv_precons);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ extern "C" {
 #endif
 /* tools/timeline.py: the registry's trace kernel (AGX_VARIANT_REGBLOCK_BASE + 70) writes 16 u64 per wave
  * (12 s_memtime phase stamps, HW_ID, XCC_ID) into this device buffer; NULL/0 turns it off. */
-int agx_ntt_debug_set_trace_buffer(void* d_buf, uint64_t bytes);
+__attribute__((visibility("default"))) int agx_ntt_debug_set_trace_buffer(void* d_buf, uint64_t bytes);
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """tools/data_dependence_probe.py -- is the headline kernel power-limited?  The SAME launch (n=4096, 4 primes, batch 4096, in place,
 4 rotating slabs) on (a) uniformly random coefficients, (b) all-zero coefficients: identical instruction stream and memory traffic,
 but no operand toggling in the multipliers.  If the board is at its power cap on (a), (b) must run faster at a higher clock and

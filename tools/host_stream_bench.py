@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """tools/host_stream_bench.py -- SURVEY 8(f3): what the host<->device streaming pipeline (agx_ntt_forward_host_stream:
 three pinned/device slots on three HIP streams, the GPU analogue of the reference's ntt_input_kernel /
 ntt_output_kernel streaming, src/kernel/ntt.cpp:508-640) achieves on >= 1 GiB of host frames, against

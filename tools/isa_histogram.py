@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """tools/isa_histogram.py -- opcode histogram of a shipped kernel's gfx950 code ("commit an opcode
 histogram of the default kernel's disassembly").  Compiles one registry translation unit to assembly with the product
 flags (hipcc --cuda-device-only -S; no GPU needed), finds the kernel whose mangled name matches PATTERN, and prints

@@ -1,7 +1,8 @@
-#!/usr/bin/env python3
 """tools/run_op.py -- launch ONE operation of the engine a fixed number of times (for rocprofv3 --pmc / --kernel-trace
 runs on paths bench.py's headline does not cover).
-Usage: python tools/run_op.py --op {fwd,inv,mul} [--n N --primes P --batch B --launches K --variant ID]"""
+Usage: python3 tools/run_op.py --op {fwd,inv,mul} [--n N --primes P --batch B --bits 60 --oop --launches K --variant ID]
+Under the profiler: rocprofv3 ... -- python3 tools/run_op.py ...   (the interpreter itself after `--`, never this file: an
+`env` shebang hop after the profiler's preload has initialised the GPU is a forbidden exec on this pool)."""
 import argparse
 import os
 import sys
@@ -20,9 +21,11 @@ ap.add_argument("--primes", type=int, default=4)
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--slabs", type=int, default=4)
 ap.add_argument("--launches", type=int, default=20)
+ap.add_argument("--bits", type=int, default=60, help="modulus size in bits")
+ap.add_argument("--oop", action="store_true", help="forward / inverse out of place (slab i -> slab i+1)")
 ap.add_argument("--variant", type=int, default=None, help="registry id (AGX_VARIANT_REGBLOCK_BASE + id)")
 args = ap.parse_args()
-plan = agx.Plan(args.n, agx.find_primes(60, args.n, args.primes))
+plan = agx.Plan(args.n, agx.find_primes(args.bits, args.n, args.primes))
 if args.variant is not None:
     plan.set_variant(agx.VARIANT_REGBLOCK_BASE + args.variant)
 stream = torch.cuda.current_stream().cuda_stream
@@ -35,10 +38,11 @@ scratch = torch.empty(per, dtype=torch.int64, device="cuda")
 
 def run(i):
     a, b = slabs[i % args.slabs], slabs[(i + 1) % args.slabs]
+    dst = b if args.oop else a
     if args.op == "fwd":
-        plan.forward(a.data_ptr(), a.data_ptr(), args.batch, stream)
+        plan.forward(a.data_ptr(), dst.data_ptr(), args.batch, stream)
     elif args.op == "inv":
-        plan.inverse(a.data_ptr(), a.data_ptr(), args.batch, stream)
+        plan.inverse(a.data_ptr(), dst.data_ptr(), args.batch, stream)
     else:
         plan.polymul(a.data_ptr(), b.data_ptr(), a.data_ptr(), scratch.data_ptr(), args.batch, stream)
 

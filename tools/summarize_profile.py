@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """tools/summarize_profile.py TAG [kernel-substring] -- condense gpurun_out/prof_TAG (written by
 tools/profile.sh on the GPU box) into profiles/TAG_summary.md and profiles/hbm_traffic.json.
 

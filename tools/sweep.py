@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """tools/sweep.py -- A/B the registered kernel configurations on the roofline workload
 (default n=4096, 4 primes, batch 4096; 4 rotating slabs; --n/--primes/--batch for other shapes), all in ONE process, interleaved rounds
 (cdna_hip_programming.md rule 24).  Every configuration's output is compared bit for bit with

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """tools/timeline.py -- where a wave of the default n=4096 kernel spends its life.
 
 Runs the registry's trace twin of the default kernel (id 70 = the default id 90 + s_memtime stamps at 12 phase
@@ -21,6 +20,8 @@ import numpy as np  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--id", type=int, default=70)
+ap.add_argument("--op", choices=["fwd", "inv"], default="fwd", help="which transform of the trace twin to stamp")
+ap.add_argument("--ref", type=int, default=None, help="registry id of the untraced kernel timed beside the twin (default 93)")
 ap.add_argument("--out", default=None)
 ap.add_argument("--raw", default=None, help="also save the raw [wave][16] stamp array and the launch timings (.npz)")
 ap.add_argument("--load", default=None, help="analyse a saved .npz instead of running on the GPU")
@@ -44,22 +45,27 @@ else:
     trace = torch.zeros(waves * 16, dtype=torch.int64, device="cuda")
     agx.debug_set_trace_buffer(trace.data_ptr(), trace.numel() * 8)
 
+    def run(slab):
+        (plan.inverse if args.op == "inv" else plan.forward)(slab.data_ptr(), slab.data_ptr(), B, stream)
+
+    ref = args.ref if args.ref is not None else 93
+
     def launches(k, count):
         plan.set_variant(agx.VARIANT_REGBLOCK_BASE + k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(count):
-            plan.forward(slabs[i % SLABS].data_ptr(), slabs[i % SLABS].data_ptr(), B, stream)
+            run(slabs[i % SLABS])
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / count
 
-    launches(90, 600)                      # clocks up
-    ms_default = launches(90, 100)
+    launches(ref, 600)                     # clocks up
+    ms_default = launches(ref, 100)
     ms_traced = launches(args.id, 100)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    plan.forward(slabs[0].data_ptr(), slabs[0].data_ptr(), B, stream)   # the launch whose stamps are kept
+    run(slabs[0])   # the launch whose stamps are kept
     e1.record()
     torch.cuda.synchronize()
     ms_last = e0.elapsed_time(e1)
@@ -88,6 +94,10 @@ ns_per_tick = ms_last * 1e6 / span      # launch duration / stamp span of the la
 names = ["entry -> frame loaded (HBM read)", "pass 0 butterflies (stages 1-3)", "exchange 0 (LDS write+read)",
          "pass 1 butterflies", "exchange 1 (LDS + the s_barrier)", "pass 2 butterflies", "exchange 2",
          "pass 3 butterflies + final reduce", "stage-out exchange", "issue stores", "stores retire (forced wait)"]
+if args.op == "inv":
+    names = ["entry -> frame loaded (HBM read)", "staging through the image (LDS write+read)", "pass 3 butterflies (per-lane twiddles)",
+             "exchange 3->2 (wave-local)", "pass 2 butterflies (per-lane twiddles)", "exchange 2->1 (wave-local)", "pass 1 butterflies",
+             "exchange 1->0 (LDS + the s_barrier)", "pass 0 butterflies + n^-1 + final reduce", "issue stores", "stores retire (forced wait)"]
 d = np.diff(ts, axis=1).astype(np.float64) * ns_per_tick
 life = (ts[:, 11] - ts[:, 0]).astype(np.float64) * ns_per_tick
 print(f"default kernel {ms_default:.4f} ms/launch, traced twin {ms_traced:.4f} ms/launch (single traced launch {ms_last:.4f} ms)")
