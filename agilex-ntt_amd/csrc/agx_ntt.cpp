@@ -32,6 +32,7 @@ struct agx_ntt_plan {
     int variant = AGX_VARIANT_AUTO;
     bool has_inverse = false;
     int arith_level = 0;     // 0 exact only; 1: every modulus <= 2^61 (8q-lazy legal); 2: <= 2^60 (16q-lazy legal)
+    int narrow_level = 0;    // 1: every modulus < 2^31, 2: < 2^30 -- the 32-bit kernels are legal (with arith_level >= 1: tables honour the contract)
     std::vector<uint64_t> moduli, psi;  // psi = 0 when the tables came from the caller
     prime_consts* d_consts = nullptr;
     ulonglong2* d_tw = nullptr;
@@ -39,10 +40,6 @@ struct agx_ntt_plan {
     ulonglong2* d_tw_rb = nullptr;
     ulonglong2* d_itw_rb = nullptr;
     regblock_layout rb;
-    regblock_layout rb_oop;            // forward layout used when out != in (fused-split kernels), or invalid
-    ulonglong2* d_tw_rb_oop = nullptr;
-    regblock_layout rb_fip;            // forward layout used when out == in (pair kernels), or invalid
-    ulonglong2* d_tw_rb_fip = nullptr;
     // {next frame, retired workgroups} pairs for the kernels that hand out frames dynamically (the loop kernels of n >= 16384; diag
     // ids 83/84), one pair per STREAM: launches on one stream run one after the other, and the last workgroup of a launch zeroes the
     // pair, so a stream's launches can share one; launches on different streams get different pairs.  Only a launcher that needs a
@@ -138,8 +135,6 @@ void free_plan(agx_ntt_plan* p) {
     if (p->d_itw) (void)hipFree(p->d_itw);
     if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
     if (p->d_itw_rb) (void)hipFree(p->d_itw_rb);
-    if (p->d_tw_rb_oop) (void)hipFree(p->d_tw_rb_oop);
-    if (p->d_tw_rb_fip) (void)hipFree(p->d_tw_rb_fip);
     delete p;
 }
 
@@ -198,10 +193,13 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
             }
         }
     }
-    p->rb = regblock_choose(n, -1, p->arith_level);
-    p->rb_oop = regblock_choose_forward_only(n, p->arith_level, false);
-    p->rb_fip = regblock_choose_forward_only(n, p->arith_level, true);
-    std::vector<ulonglong2> rb_pairs, irb_pairs, oop_pairs, fip_pairs;
+    p->narrow_level = 2;
+    for (uint32_t k = 0; k < num_primes; ++k) {
+        if (moduli[k] >= (1ull << 30)) p->narrow_level = std::min(p->narrow_level, 1);
+        if (moduli[k] >= (1ull << 31)) p->narrow_level = 0;
+    }
+    p->rb = regblock_choose(n, -1, p->arith_level, p->narrow_level);
+    std::vector<ulonglong2> rb_pairs, irb_pairs;
     for (uint32_t k = 0; k < num_primes; ++k) {
         const uint64_t q = moduli[k];
         prime_consts& c = consts[k];
@@ -232,8 +230,6 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
             if (p->rb.valid()) regblock_build_table(p->rb, itwk, iprek, irb_pairs);
         }
         if (p->rb.valid()) regblock_build_table(p->rb, twk, prek, rb_pairs);
-        if (p->rb_oop.valid()) regblock_build_table(p->rb_oop, twk, prek, oop_pairs);
-        if (p->rb_fip.valid()) regblock_build_table(p->rb_fip, twk, prek, fip_pairs);
     }
     if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
     {
@@ -245,8 +241,6 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     if (itw && (rc = upload(&p->d_itw, itw_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && (rc = upload(&p->d_tw_rb, rb_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && itw && (rc = upload(&p->d_itw_rb, irb_pairs)) != AGX_OK) { free_plan(p); return rc; }
-    if (p->rb_oop.valid() && (rc = upload(&p->d_tw_rb_oop, oop_pairs)) != AGX_OK) { free_plan(p); return rc; }
-    if (p->rb_fip.valid() && (rc = upload(&p->d_tw_rb_fip, fip_pairs)) != AGX_OK) { free_plan(p); return rc; }
     *out = p;
     return AGX_OK;
 }
@@ -433,7 +427,7 @@ static int plan_set_variant_impl(agx_ntt_plan* plan, int variant) {
     if (variant != AGX_VARIANT_AUTO && variant != AGX_VARIANT_LDS_RADIX2 && variant != AGX_VARIANT_REGBLOCK) return AGX_ERR_BAD_ARGUMENT;
     if (variant == AGX_VARIANT_REGBLOCK || variant == AGX_VARIANT_AUTO) {
         // (re)build the pass tables for the requested kernel configuration
-        const regblock_layout rb = regblock_choose(plan->n, config_id, plan->arith_level);
+        const regblock_layout rb = regblock_choose(plan->n, config_id, plan->arith_level, plan->narrow_level);
         if (!rb.valid()) {
             if (variant == AGX_VARIANT_REGBLOCK) return AGX_ERR_BAD_SIZE;
         } else if (rb.config_id != plan->rb.config_id) {
@@ -462,15 +456,6 @@ static int plan_set_variant_impl(agx_ntt_plan* plan, int variant) {
             plan->d_itw_rb = d_new[1];
             plan->rb = rb;
         }
-    }
-    if (config_id >= 0) {
-        plan->rb_oop = regblock_layout{};            // an explicit kernel choice applies to every call
-        plan->rb_fip = regblock_layout{};
-    } else if (variant != AGX_VARIANT_LDS_RADIX2) {  // tables were built at creation
-        const regblock_layout oop = regblock_choose_forward_only(plan->n, plan->arith_level, false);
-        const regblock_layout fip = regblock_choose_forward_only(plan->n, plan->arith_level, true);
-        if (oop.valid() && plan->d_tw_rb_oop) plan->rb_oop = oop;
-        if (fip.valid() && plan->d_tw_rb_fip) plan->rb_fip = fip;
     }
     plan->variant = variant;
     return AGX_OK;
@@ -502,19 +487,6 @@ static int forward_common(const agx_ntt_plan* plan, const uint64_t* d_in, uint64
     fl.lazy_out = lazy_out;
     plan_view pv = view_of(plan);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // forward-only layouts, where n has them.  n = 16384: measured faster than the one-workgroup-per-CU
-    // main kernel only while the launch is too small to fill the chip several times over (2,048 frames:
-    // +7..11 %; 8,192 frames and up: -4..6 %); n = 32768 out of place: always faster (+17 %).
-    const bool few_frames = batch * plan->num_primes < 4096;
-    if (plan->variant != AGX_VARIANT_LDS_RADIX2 && (plan->log_n != 14 || few_frames)) {
-        if (d_in != d_out && plan->rb_oop.valid()) {
-            pv.rb = plan->rb_oop;
-            pv.tw_rb = plan->d_tw_rb_oop;
-        } else if (d_in == d_out && plan->rb_fip.valid()) {
-            pv.rb = plan->rb_fip;
-            pv.tw_rb = plan->d_tw_rb_fip;
-        }
-    }
     AGX_HIP(use_regblock(plan) ? launch_forward_regblock(pv, d_in, d_out, fl, s) : launch_forward_radix2(pv, d_in, d_out, fl, s));
     return AGX_OK;
 }

@@ -217,10 +217,9 @@ namespace {
 // every group of the registry, one per translation unit
 template <class F>
 void for_each_entry(F&& f) {
-    const rb_span groups[] = {rb_entries_n4096(), rb_entries_n4096_ab(), rb_entries_n1024(), rb_entries_n2048(), rb_entries_n8192(),
-                              rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_r5(), rb_entries_gen1(),
+    const rb_span groups[] = {rb_entries_n4096(), rb_entries_n1024(), rb_entries_n2048(), rb_entries_n8192(), rb_entries_r5(), rb_entries_q32(),
 #ifdef AGX_DIAG
-                              rb_entries_diag(),
+                              rb_entries_n4096_ab(), rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_gen1(), rb_entries_diag(),
 #endif
     };
     for (const rb_span& g : groups)
@@ -247,7 +246,7 @@ hipError_t set_lds_attr(F* fn, size_t bytes) {
 
 }  // namespace
 
-regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
+regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int narrow_level) {
     regblock_layout rb;
     int log_n = 0;
     while ((1u << log_n) < n) ++log_n;
@@ -256,19 +255,24 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
     auto split_for = [&](const rb_entry& e) -> int {
         if (e.fused_split > 0) return e.log_local + e.fused_split == log_n ? e.fused_split : -1;
         if (e.log_local == log_n) return 0;      // whole frame resident (n = 32768: split-word image)
+        if (e.whole_only) return -1;
         const int split = log_n > kMaxLdsLog ? log_n - kMaxLdsLog : 0;
         return e.log_local + split == log_n ? split : -1;
     };
+    // a 32-bit entry is legal when every modulus fits its tier and the tables honour the precon contract
+    auto legal = [&](const rb_entry& c) { return c.arith <= arith_level && (c.narrow == 0 || (arith_level >= 1 && narrow_level >= (c.narrow == 2 ? 2 : 1))); };
     const rb_entry* e = nullptr;
     if (config_id >= 0) {
         e = rb_lookup(config_id);
-        if (e && (split_for(*e) < 0 || e->arith > arith_level)) e = nullptr;
+        if (e && (split_for(*e) < 0 || !legal(*e))) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
-        static const int kDefaults[] = {93, 90, 92, 91, 50, 39, 27, 28, 63, 61, 40, 29, 30, 59, 41, 31, 32, 64, 42, 33, 34, 43, 35, 36, 2};
+        static const int kDefaults[] = {130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141,      // narrow moduli: 32-bit arithmetic (tier 2, then tier 1)
+                                        93, 92, 91, 63, 29, 30, 59, 31, 32, 64, 33, 34,                 // n = 1024 ... 8192: 16q-lazy, fast, exact
+                                        119, 117, 121, 120, 123, 122};                                  // n = 32768 / 16384: whole-frame R = 5 kernels
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
-            if (c && split_for(*c) >= 0 && c->arith <= arith_level) { e = c; break; }
+            if (c && split_for(*c) >= 0 && legal(*c)) { e = c; break; }
         }
     }
     if (!e) return rb;
@@ -279,25 +283,6 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level) {
     rb.r = e->r;
     rb.pairs_per_prime = e->table_pairs << rb.log_split;
     return rb;
-}
-
-// tuned forward-only configurations for the sizes whose frames exceed one 8-waves/SIMD workgroup:
-// out of place a fused-split kernel (every block may read the whole frame), in place a pair kernel;
-// invalid layout when n has none (the plan's main layout then serves forward calls too)
-regblock_layout regblock_choose_forward_only(uint32_t n, int arith_level, bool in_place) {
-    static const int kOop[] = {46, 45, 44, 49, 48, 47};   // fused-split kernels: every block reads the whole frame
-    static const int kInPlace[] = {53, 52, 51, 54, 55, 56};           // pair kernels: a workgroup owns the whole frame
-    for (int id : kInPlace) {
-        if (!in_place) break;
-        regblock_layout rb = regblock_choose(n, id, arith_level);
-        if (rb.valid()) return rb;
-    }
-    if (in_place) return regblock_layout{};
-    for (int id : kOop) {
-        regblock_layout rb = regblock_choose(n, id, arith_level);
-        if (rb.valid()) return rb;
-    }
-    return regblock_layout{};
 }
 
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {

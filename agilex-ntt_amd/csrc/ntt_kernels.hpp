@@ -53,8 +53,9 @@ struct frame_layout {
 // natural-index tables; appends rb.pairs_per_prime pairs to `out`
 // config_id -1: tuned default for n; arith_level: 0 exact only, 1 every modulus <= 2^61 (fast form legal),
 // 2 every modulus <= 2^60 (16q-lazy form legal)
-regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level);
-regblock_layout regblock_choose_forward_only(uint32_t n, int arith_level, bool in_place);   // forward-only layouts or invalid
+// narrow_level: 0 some modulus >= 2^31; 1 every modulus < 2^31; 2 every modulus < 2^30 (the 32-bit kernels of rb32_kernels.hpp; they
+// also need arith_level >= 1, i.e. tables that honour the precon contract)
+regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int narrow_level = 0);
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out);
 
 hipError_t kernels_init();  // one-time function attributes (large dynamic LDS)

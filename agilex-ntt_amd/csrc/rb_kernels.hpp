@@ -2009,6 +2009,7 @@ constexpr rb_entry make_entry_single(int id) {
                (ARITH & 1) ? ((((ARITH >> 1) & kOptLazy16) != 0) ? 2 : 1) : 0,
                &launch_inv_rb2_t<L, R, 1, ARITH, MINW>, &launch_mul_park_t<L, R, ARITH, MINW>, 0, nullptr, false};
     e.mul_parked = true;
+    e.whole_only = true;       // the streamed inverse folds n^-1 into its top stage
     return e;
 }
 

@@ -30,6 +30,8 @@ struct rb_entry {
     // whole-frame inverse (log_split = 0) by a resident grid walking over the frames, or null
     hipError_t (*launch_inv_loop)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t) = nullptr;
     bool mul_parked = false;   // launch_mul keeps one frame in registers (the other parked in c's frame): legal at every log_local
+    bool whole_only = false;   // the kernels assume the whole frame is resident (log_split = 0): never serves n = 2^(log_local + k)
+    int narrow = 0;            // 0: 64-bit arithmetic; 1: 32-bit arithmetic, every modulus < 2^31; 2: every modulus < 2^30 (rb32_kernels.hpp)
 };
 
 struct rb_span {
@@ -38,17 +40,20 @@ struct rb_span {
 };
 
 // one group per translation unit, so the ~50 kernel instantiations compile in parallel
-rb_span rb_entries_gen1();
+// product groups (their A/B extras are compiled in under AGX_DIAG)
 rb_span rb_entries_n1024();
 rb_span rb_entries_n2048();
 rb_span rb_entries_n4096();
-rb_span rb_entries_n4096_ab();
 rb_span rb_entries_n8192();
+rb_span rb_entries_r5();
+rb_span rb_entries_q32();
+#ifdef AGX_DIAG
+// groups that only exist in lib/libagxntt_diag.so: earlier generations and measured-and-rejected shapes, kept selectable for A/B runs
+rb_span rb_entries_gen1();
+rb_span rb_entries_n4096_ab();
 rb_span rb_entries_n8192_split();
 rb_span rb_entries_n8192_pair();
 rb_span rb_entries_n16384();
-rb_span rb_entries_r5();
-#ifdef AGX_DIAG
 rb_span rb_entries_diag();                                      // trace twin, streaming A/B kernels, timing ablations
 hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves);   // where the trace kernels write
 #endif

@@ -6,10 +6,14 @@
 namespace agx {
 namespace AGX_TU {
 // n = 4096 defaults: wave priority raised from launch until the frame's one all-wave barrier has been passed (+2 %);
-// 90 = 16q-lazy (q <= 2^60), 92 = fast (q <= 2^61), 91 = exact (q < 2^62); 66 = R = 4 in three passes at 4 waves/SIMD (A/B, within 1.5 % of 90)
+// 93 = 16q-lazy with the tail-free subtract schedule and quotient-estimate final reduction (q <= 2^60), 92 = fast (q <= 2^61), 91 = exact (q < 2^62)
 const rb_entry kEntries[] = {
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore) << 1), 8>(90),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8>(93),   // 90 + tail-free subtract schedule and quotient-estimate final reduction
+    make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
+#ifdef AGX_DIAG
+    // A/B entries (lib/libagxntt_diag.so only): no default and no call-shape selector reaches them
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore) << 1), 8>(90),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptMulLoCross) << 1), 8>(87),     // A/B: 93 with the cross products as 32-bit multiplies (-3 % energy per butterfly in tools/microbench pwr)
     make_entry2<12, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 4>(66),   // A/B: R = 4 (three passes, 4-wave workgroups) at 4 waves/SIMD, within 1.5 % of id 90
     // A/B (forward only): R = 4, 256-thread workgroups, split-word exchanges through a 17 KiB image -> up to 8 workgroups per CU;
@@ -27,8 +31,7 @@ const rb_entry kEntries[] = {
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptInvPrioTail) << 1), 8>(103),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptInvPrioAsc) << 1), 8>(104),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptInvPrioDesc) << 1), 8>(105),
-    make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
+#endif
 };
 }  // namespace AGX_TU
 

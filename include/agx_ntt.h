@@ -143,8 +143,8 @@ AGX_API int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, con
                       uint64_t batch, void* stream);
 /* c = a * b in Z_q[X]/(X^n + 1) = INTT(NTT(a) o NTT(b)); dense layout; c may alias a or b.
  * d_scratch: num_primes*batch*n elements of device memory owned by the caller, distinct from a, b, c.
- * It is only used when n has no one-launch fused kernel -- today n < 1024 and n >= 16384 -- and may be NULL
- * otherwise (1024 <= n <= 8192); a NULL scratch where one is needed returns AGX_ERR_NULL_POINTER. */
+ * It is only used when n has no one-launch fused kernel -- today n < 1024 (and plans forced onto the radix-2 kernels) -- and
+ * may be NULL otherwise (1024 <= n <= 32768); a NULL scratch where one is needed returns AGX_ERR_NULL_POINTER. */
 AGX_API int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                     uint64_t* d_scratch, uint64_t batch, void* stream);
 

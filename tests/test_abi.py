@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol(agx):
         assert hasattr(raw, name), name
 
 
+def test_library_exports_nothing_but_the_c_abi(agx):
+    """built with -fvisibility=hidden and csrc/exports.map: the dynamic symbol table holds the agx_ntt_* entry points only (no
+    C++ internals, no kernel host stubs), and exactly the ones the header declares"""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", agx.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert names == _declared_symbols(), [n for n in names if not n.startswith("agx_ntt_")][:10]
+
+
 def test_no_torch_or_oracle_in_product_library(agx):
     """the shipped library links neither torch nor the oracle"""
     import subprocess

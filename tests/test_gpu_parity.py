@@ -14,6 +14,22 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL_SIZES = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768]
 
 
+# registry ids of the product library (what a default or a call-shape selector can reach); every other id is an A/B entry that
+# only lib/libagxntt_diag.so carries: tests/test_gpu_diag.py re-runs the id-parametrised tests of this file in a child process
+# bound to that library
+PRODUCT_IDS = {93, 92, 91, 63, 29, 30, 59, 31, 32, 64, 33, 34, 117, 119, 120, 121, 122, 123} | set(range(130, 142))
+
+
+def _select(agx, plan, config):
+    """explicit registry entry (AGX_VARIANT_REGBLOCK_BASE + id); A/B ids are skipped unless the diag library is loaded"""
+    if config is None or config == "default":
+        return
+    if config not in PRODUCT_IDS and not agx.LIB_PATH.endswith("libagxntt_diag.so"):
+        plan.close()
+        pytest.skip(f"registry id {config} lives in lib/libagxntt_diag.so (covered by tests/test_gpu_diag.py)")
+    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+
+
 def _plan_from_oracle_tables(agx, orc, n, bits, count, inverse=True):
     tabs = tables_for(orc, n, bits, count)
     tw = np.stack([t[2] for t in tabs])
@@ -179,12 +195,15 @@ def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
         # fast forms need q <= 2^61, the 16q-lazy form q <= 2^60: anything else must be refused
         illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 86, 89, 90, 93) and bits >= 61)
         if illegal:
+            if config not in PRODUCT_IDS and not agx.LIB_PATH.endswith("libagxntt_diag.so"):
+                plan.close()
+                pytest.skip("diag-library id")
             with pytest.raises(agx.AgxError) as ei:
                 plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
             assert ei.value.status == 2
             plan.close()
             return
-        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+        _select(agx, plan, config)
     rng = np.random.default_rng(bits * 100 + (config if config != "default" else 7))
     x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4 if bits < 62 else 3) for t in tabs])
     d = dev.to_device(x)
@@ -439,9 +458,9 @@ def test_empty_batch_and_errors(agx, dev):
     with pytest.raises(agx.AgxError) as ei:
         fwd_only.inverse(d.data_ptr(), d.data_ptr(), 1, dev.stream)
     assert ei.value.status == 9
-    # poly-mul: a size without a one-launch kernel needs caller scratch (NULL -> 1), scratch must be distinct (-> 5)
-    big = agx.Plan(16384, [agx.find_primes(60, 16384)[0]])
-    e = dev.empty(16384)
+    # poly-mul: a size without a one-launch kernel (n < 1024) needs caller scratch (NULL -> 1), scratch must be distinct (-> 5)
+    big = agx.Plan(512, [agx.find_primes(60, 512)[0]])
+    e = dev.empty(512)
     for scratch, status in ((0, 1), (e.data_ptr(), 5)):
         with pytest.raises(agx.AgxError) as ei:
             big.polymul(e.data_ptr(), e.data_ptr(), e.data_ptr(), scratch, 1, dev.stream)
@@ -643,13 +662,12 @@ def _oracle_polymul(orc, a, b, q, psi, n):
 
 
 @pytest.mark.parametrize("bits", [60, 61, 62])
-@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 32768])
 def test_polymul_every_fused_kernel(agx, orc, dev, n, bits):
-    """agx_ntt_polymul at every size with a fused path, in the 16q-lazy (60-bit), fast (61-bit) and exact (62-bit)
-    arithmetic: the one-launch polymul_rb2 kernels for n <= 8192 (registry defaults 61/41/90/64 and their fast /
-    exact siblings) and, at n = 16384, two lazy forward launches + the inverse kernel that multiplies while it
-    loads (in2 != NULL).  Expected: schoolbook product for n <= 2048, the oracle's NTT pipeline above that;
-    c distinct, c aliasing a, c aliasing b."""
+    """agx_ntt_polymul at every size with a one-launch kernel, in the 16q-lazy (60-bit), fast (61-bit) and exact (62-bit)
+    arithmetic: polymul_rb2 (two frames in registers) for n <= 8192 and polymul_rb2_park (one frame in registers, the other
+    parked in c's frame) of the R = 5 kernels at n = 16384 / 32768.  Expected: schoolbook product for n <= 2048, the oracle's
+    NTT pipeline above that; c distinct, c aliasing a, c aliasing b."""
     batch, primes = 3, 2
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
     rng = np.random.default_rng(n * 7 + bits)
@@ -672,12 +690,14 @@ def test_polymul_every_fused_kernel(agx, orc, dev, n, bits):
     plan.close()
 
 
-def test_one_launch_product_at_16384_with_aliasing_and_no_scratch(agx, orc, dev):
-    """registry id 37's fused product at n=16384 (polymul_rb2_park: NTT of the operand c aliases is parked in c's own frame, the
-    other transform stays in registers): no caller scratch, c distinct / aliasing a / aliasing b, operands in [0,4q), two primes"""
-    n, batch, primes = 16384, 5, 2
+@pytest.mark.parametrize("n,config", [(16384, None), (32768, None), (16384, 37), (16384, 120), (32768, 123)])
+def test_one_launch_product_with_aliasing_and_no_scratch(agx, orc, dev, n, config):
+    """the parked-operand fused product (polymul_rb2_park) at n = 16384 / 32768 -- the R = 5 defaults park NTT(first) thread-privately
+    in c's own frame, registry id 37 (R = 4, A/B) parks it in natural order and redistributes through LDS; 120 / 123: the fast /
+    exact forms under a 60-bit modulus: no caller scratch, c distinct / aliasing a / aliasing b, operands in [0,4q), two primes"""
+    batch, primes = 5, 2
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
-    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + 37)
+    _select(agx, plan, config)
     rng = np.random.default_rng(3700)
     a = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
     b = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
@@ -719,12 +739,19 @@ def test_polymul_lazy_operands(agx, orc, dev):
 REGISTRY = [
     (2, 4096, 62), (12, 4096, 61), (13, 4096, 62), (27, 4096, 61), (28, 4096, 62), (39, 4096, 60), (50, 4096, 60),
     (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61), (93, 4096, 60), (86, 4096, 60), (89, 4096, 60), (87, 4096, 60), (97, 4096, 60), (98, 4096, 60),
+    (101, 4096, 60), (102, 4096, 60), (103, 4096, 60), (104, 4096, 60), (105, 4096, 60), (106, 4096, 60), (107, 4096, 60),
     (29, 1024, 61), (30, 1024, 62), (40, 1024, 60), (61, 1024, 60), (62, 1024, 60), (63, 1024, 60),
     (31, 2048, 61), (32, 2048, 62), (41, 2048, 60), (59, 2048, 60), (94, 4096, 60), (95, 4096, 60), (96, 4096, 60),
     (33, 8192, 61), (34, 8192, 62), (42, 8192, 60), (64, 8192, 60), (65, 8192, 60),
     (35, 16384, 61), (36, 16384, 62), (43, 16384, 60), (57, 16384, 60), (58, 16384, 60), (37, 16384, 60),
     (44, 16384, 62), (45, 16384, 61), (46, 16384, 60), (47, 32768, 62), (48, 32768, 61), (49, 32768, 60),
     (51, 16384, 62), (52, 16384, 61), (53, 16384, 60), (54, 32768, 60), (55, 32768, 61), (56, 32768, 62),
+    # whole-frame R = 5 kernels (117 / 119 defaults, 120-123 fast / exact forms, 114-116 / 118 A/B)
+    (117, 16384, 60), (119, 32768, 60), (120, 16384, 61), (121, 32768, 61), (122, 16384, 62), (123, 32768, 62),
+    (114, 32768, 60), (115, 16384, 60), (116, 32768, 60), (118, 16384, 60),
+    # 32-bit arithmetic: tier 2 (every q < 2^30), tier 1 (every q < 2^31)
+    (130, 1024, 30), (131, 2048, 30), (132, 4096, 30), (133, 8192, 30), (134, 16384, 30), (135, 32768, 30),
+    (136, 1024, 31), (137, 2048, 31), (138, 4096, 31), (139, 8192, 31), (140, 16384, 31), (141, 32768, 31),
 ]
 
 
@@ -736,7 +763,7 @@ def test_every_registry_entry_at_its_own_size(agx, orc, dev, config, n, max_bits
     batch = 3
     for bits in (max_bits, 30):
         plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, 1)
-        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+        _select(agx, plan, config)
         q, psi, tw, pre = tabs[0]
         rng = np.random.default_rng(config * 131 + bits)
         x = rand_coeffs(rng, batch * n, q, hi_mult=4 if bits < 62 else 3)
@@ -757,14 +784,15 @@ def test_every_registry_entry_at_its_own_size(agx, orc, dev, config, n, max_bits
         plan.close()
 
 
-@pytest.mark.parametrize("config", [43, 57, 37])
-def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config):
-    """the loop kernels (a resident grid of one workgroup per CU walking over the frames -- 43: the n=16384 default, inverse by
-    the ticket-drawing loop kernel; 37: forward too; 57: both with a fixed stride) on more frames than the chip holds workgroups, a frame count that is not
-    a multiple of the grid, two primes, in place: forward and inverse against the oracle"""
-    n, batch, primes = 16384, 333, 2
+@pytest.mark.parametrize("config,n,batch", [(117, 16384, 333), (119, 32768, 290), (118, 16384, 333), (116, 32768, 290), (43, 16384, 333), (57, 16384, 333), (37, 16384, 333)])
+def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config, n, batch):
+    """the loop kernels (a resident grid walking over the frames -- 117 / 119: the n = 16384 / 32768 defaults, inverse by the
+    ticket-drawing loop kernel; 118 / 116: forward too; 43 / 37 / 57: the R = 4 generation, ticket-drawing and fixed-stride) on more
+    frames than the chip holds workgroups, a frame count that is not a multiple of the grid, two primes, in place: forward and
+    inverse against the oracle"""
+    primes = 2
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
-    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+    _select(agx, plan, config)
     rng = np.random.default_rng(config + 1000)
     x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
     d = dev.to_device(x)
@@ -779,14 +807,15 @@ def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config):
     plan.close()
 
 
-def test_dynamic_loop_kernels_on_two_streams_of_one_plan(agx, orc, dev):
-    """the ticket-drawing loop kernels (registry id 37) launched back to back on two streams of ONE plan, so that launches
-    overlap: every launch takes its own ticket pair from the plan's ring, so both results must be right, repeatedly"""
+@pytest.mark.parametrize("config", [117, 118, 37])
+def test_dynamic_loop_kernels_on_two_streams_of_one_plan(agx, orc, dev, config):
+    """the ticket-drawing loop kernels (117: the default's inverse; 118 / 37: forward too) launched back to back on two streams of ONE
+    plan, so that launches overlap: the plan keeps one ticket pair per stream, so both results must be right, repeatedly"""
     import torch
 
     n, batch = 16384, 700
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, 1)
-    plan.set_variant(agx.VARIANT_REGBLOCK_BASE + 37)
+    _select(agx, plan, config)
     q, psi, tw, pre = tabs[0]
     rng = np.random.default_rng(3737)
     xa, xb = rand_coeffs(rng, batch * n, q), rand_coeffs(rng, batch * n, q)
@@ -806,15 +835,12 @@ def test_dynamic_loop_kernels_on_two_streams_of_one_plan(agx, orc, dev):
     plan.close()
 
 
-@pytest.mark.parametrize("n,config,batch", [(32768, None, 1100), (16384, 53, 2100)])
-def test_pair_kernels_on_many_frames(agx, orc, dev, n, config, batch):
-    """the two-halves-in-turn kernels (n=32768: default in-place forward and one-launch inverse; n=16384: registry id 53) on
-    several rounds of workgroups per CU: forward in place and inverse against the oracle.  (A loop form of these kernels was
-    measured and dropped: the loop state pushes their already spilling register allocation from 76 to 228 bytes of scratch
-    per lane, -19 % at n=32768.)"""
+@pytest.mark.parametrize("n,config,batch", [(32768, None, 1100), (16384, None, 2100), (32768, 54, 1100), (16384, 53, 2100)])
+def test_large_frames_on_many_rounds_of_workgroups(agx, orc, dev, n, config, batch):
+    """n = 32768 / 16384 on several rounds of workgroups per CU: the whole-frame R = 5 defaults and the two-halves-in-turn kernels
+    they replaced (registry ids 54 / 53, A/B): forward in place and inverse against the oracle"""
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, 1)
-    if config is not None:
-        plan.set_variant(agx.VARIANT_REGBLOCK_BASE + config)
+    _select(agx, plan, config)
     q, psi, tw, pre = tabs[0]
     rng = np.random.default_rng(n + batch)
     x = rand_coeffs(rng, batch * n, q, hi_mult=4)
@@ -828,6 +854,196 @@ def test_pair_kernels_on_many_frames(agx, orc, dev, n, config, batch):
     plan.inverse(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
     assert np.array_equal(dev.to_host(d_r), orc.inverse(r % np.uint64(q), q, orc.make_inv_tables(q, psi, n)[0], n))
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------
+# narrow moduli: the 32-bit arithmetic kernels (csrc/rb32_kernels.hpp)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bits", [17, 20, 30, 31])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 32768])
+def test_narrow_modulus_kernels(agx, orc, dev, n, bits):
+    """plans whose every modulus is below 2^31 take the 32-bit Shoup / Harvey kernels (tier 2 below 2^30, tier 1 below 2^31): the
+    reference's own modulus class (src/main.cpp:55 is 65537; BASELINE configs[0] is a 30-bit prime).  Against the oracle, which
+    computes in 64 bits: forward out of place / in place / lazy on inputs anywhere in [0,4q), inverse of lazy inputs and round
+    trip, fused product with c aliasing either operand, worst-case inputs (all 4q-1, all q-1, alternating); ragged batch."""
+    batch = 5 if n <= 4096 else 3
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, 1)
+    q, psi, tw, pre = tabs[0]
+    assert q < (1 << bits) and q >= 3
+    itw = orc.make_inv_tables(q, psi, n)[0]
+    rng = np.random.default_rng(n * 31 + bits)
+    x = rand_coeffs(rng, batch * n, q, hi_mult=4)
+    want = orc.forward(x, q, tw, pre, n)
+    d_x, d_y = dev.to_device(x), dev.empty(x.size)
+    plan.forward(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_y), want), "out of place"
+    assert np.array_equal(dev.to_host(d_x), x), "input must not be modified"
+    plan.forward_lazy(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+    lazy = dev.to_host(d_y)
+    assert (lazy < np.uint64(4 * q)).all() and np.array_equal(lazy % np.uint64(q), want), "lazy outputs"
+    plan.inverse(d_y.data_ptr(), d_y.data_ptr(), batch, dev.stream)          # lazy values are legal inverse inputs
+    assert np.array_equal(dev.to_host(d_y), x % np.uint64(q)), "round trip"
+    plan.forward(d_x.data_ptr(), d_x.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_x), want), "in place"
+    r = rand_coeffs(rng, batch * n, q, hi_mult=4)
+    d_r = dev.to_device(r)
+    plan.inverse(d_r.data_ptr(), d_r.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_r), orc.inverse(r % np.uint64(q), q, itw, n)), "inverse"
+    # worst cases of the lazy ranges
+    top = 4 * q - 1
+    e = np.concatenate([np.full(n, top, dtype=np.uint64), np.full(n, q - 1, dtype=np.uint64),
+                        np.where(np.arange(n) % 2 == 0, np.uint64(top), np.uint64(0))])
+    d_e = dev.to_device(e)
+    plan.forward(d_e.data_ptr(), d_e.data_ptr(), 3, dev.stream)
+    assert np.array_equal(dev.to_host(d_e), orc.forward(e, q, tw, pre, n)), "extreme forward"
+    d_e = dev.to_device(e)
+    plan.inverse(d_e.data_ptr(), d_e.data_ptr(), 3, dev.stream)
+    assert np.array_equal(dev.to_host(d_e), orc.inverse(e % np.uint64(q), q, itw, n)), "extreme inverse"
+    # fused product, operands in [0,4q)
+    a, b = rand_coeffs(rng, batch * n, q, hi_mult=4), rand_coeffs(rng, batch * n, q, hi_mult=4)
+    a[:n] = top
+    b[:n] = top
+    wantc = np.concatenate([orc.schoolbook(a[f * n:(f + 1) * n] % np.uint64(q), b[f * n:(f + 1) * n] % np.uint64(q), q, n) if n <= 2048
+                            else _oracle_polymul(orc, a[f * n:(f + 1) * n], b[f * n:(f + 1) * n], q, psi, n) for f in range(batch)])
+    d_a, d_b, d_c = dev.to_device(a), dev.to_device(b), dev.empty(a.size)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_c), wantc), "product"
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_a.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_a), wantc), "product, c aliasing a"
+    d_a = dev.to_device(a)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_b.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_b), wantc), "product, c aliasing b"
+    plan.close()
+
+
+@pytest.mark.parametrize("bits_list", [(30, 31), (17, 30, 20), (30, 60), (31, 31)])
+def test_narrow_and_mixed_modulus_plans(agx, orc, dev, bits_list):
+    """RNS plans mixing modulus sizes: (30, 31) -> the tier-1 32-bit kernels for every prime, (17, 30, 20) -> tier 2, (30, 60) -> the
+    64-bit kernels (one modulus is wide); strided [poly][prime][n] layout with an odd offset (8-byte aligned frames only: the
+    narrow kernels must then take their 8-byte access path), forward and inverse against the oracle per prime"""
+    n, batch = 4096, 4
+    used, tabs = set(), []
+    for b in bits_list:
+        k = 0
+        while orc.find_prime(b, n, k) in used:
+            k += 1
+        q = orc.find_prime(b, n, k)
+        used.add(q)
+        psi = orc.min_root(q, n)
+        tabs.append((q, psi) + tuple(orc.make_tables(q, psi, n)))
+    primes = len(tabs)
+    inv = [orc.make_inv_tables(t[0], t[1], n) for t in tabs]
+    plan = agx.Plan(n, [t[0] for t in tabs], tables=(np.stack([t[2] for t in tabs]), np.stack([t[3] for t in tabs]),
+                                                      np.stack([i[0] for i in inv]), np.stack([i[1] for i in inv])))
+    rng = np.random.default_rng(sum(bits_list))
+    poly_stride, prime_stride, off = primes * n + 6, n + 2, 1          # odd offset: frames are only 8-byte aligned
+    buf = np.zeros(off + batch * poly_stride, dtype=np.uint64)
+    want = np.zeros_like(buf)
+    for p, t in enumerate(tabs):
+        for b in range(batch):
+            lo = off + b * poly_stride + p * prime_stride
+            buf[lo:lo + n] = rand_coeffs(rng, n, t[0], hi_mult=4)
+            want[lo:lo + n] = orc.forward(buf[lo:lo + n], t[0], t[2], t[3], n)
+    d = dev.to_device(buf)
+    ptr = d.data_ptr() + 8 * off
+    plan.forward_strided(ptr, ptr, batch, prime_stride, poly_stride, dev.stream)
+    got = dev.to_host(d)
+    assert np.array_equal(got, want)          # gaps between frames untouched (zero)
+    plan.inverse_strided(ptr, ptr, batch, prime_stride, poly_stride, dev.stream)
+    back = dev.to_host(d)
+    for p, t in enumerate(tabs):
+        for b in range(batch):
+            lo = off + b * poly_stride + p * prime_stride
+            assert np.array_equal(back[lo:lo + n], buf[lo:lo + n] % np.uint64(t[0])), (p, b)
+    plan.close()
+
+
+def test_out_of_contract_tables_stay_on_the_exact_kernels(agx, orc, dev):
+    """a narrow modulus with tables that do NOT honour precon = floor(w 2^64 / q) (here: precons off by one) must not take the 32-bit
+    (or any lazy) kernels: the exact kernels repeat the reference's operations mod 2^64 on whatever they are fed, as the oracle does"""
+    n, batch = 4096, 2
+    q = orc.find_prime(30, n)
+    psi = orc.min_root(q, n)
+    tw, pre = orc.make_tables(q, psi, n)
+    bad = pre.copy()
+    bad[5] -= np.uint64(1)
+    plan = agx.Plan(n, [q], tables=(tw[None, :], bad[None, :]))
+    x = rand_coeffs(np.random.default_rng(5), batch * n, q)
+    d = dev.to_device(x)
+    plan.forward(d.data_ptr(), d.data_ptr(), batch, dev.stream)
+    assert np.array_equal(dev.to_host(d), orc.forward(x, q, tw, bad, n))
+    plan.close()
+
+
+def test_more_streams_than_ticket_slots(agx, orc, dev):
+    """a plan keeps one {ticket, retired} pair per stream for 64 streams; launches on further streams must take the stateless
+    fixed-stride kernels -- every result right, on 70 streams of one plan, twice (a wrapped ticket ring let two
+    launches in flight share one counter and skip frames silently)"""
+    import torch
+
+    n, batch = 16384, 300
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, 1)
+    q, psi, tw, pre = tabs[0]
+    itw = orc.make_inv_tables(q, psi, n)[0]
+    rng = np.random.default_rng(64)
+    r = rand_coeffs(rng, batch * n, q, hi_mult=4)
+    want = orc.inverse(r % np.uint64(q), q, itw, n)
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    for rep in range(2):
+        bufs = [dev.to_device(r) for _ in range(4)]
+        dev.sync()
+        for i, st in enumerate(streams):
+            b = bufs[i % 4]
+            if i >= 4:
+                st.wait_stream(streams[i - 4])          # the buffer's previous user: inverse of an inverse is not what we check
+                continue
+            plan.inverse(b.data_ptr(), b.data_ptr(), batch, st.cuda_stream)
+        dev.sync()
+        for b in bufs:
+            assert np.array_equal(dev.to_host(b), want), rep
+        # and one launch per stream, each on a buffer of its own turn (sequential: 70 distinct streams touch the plan's slot table)
+        for i, st in enumerate(streams):
+            b = dev.to_device(r)
+            plan.inverse(b.data_ptr(), b.data_ptr(), batch, st.cuda_stream)
+            st.synchronize()
+            assert np.array_equal(dev.to_host(b), want), (rep, i)
+    plan.close()
+
+
+def test_one_shot_calls_from_two_threads_with_different_tables(agx, orc):
+    """agx_ntt_forward_host from two host threads at once, each alternating between two table sets (so the per-device plan
+    cache is evicted again and again): every result against the oracle (one global slot leaked / serialised)"""
+    import threading
+
+    n, frames = 2048, 6
+    cases = []
+    for k, bits in enumerate((30, 60, 45, 31)):
+        q = orc.find_prime(bits, n)
+        psi = orc.min_root(q, n)
+        tw, pre = orc.make_tables(q, psi, n)
+        x = rand_coeffs(np.random.default_rng(k), frames * n, q)
+        cases.append((q, tw, pre, x, orc.forward(x, q, tw, pre, n)))
+    errors = []
+
+    def worker(mine):
+        try:
+            for rep in range(6):
+                q, tw, pre, x, want = cases[mine[rep % 2]]
+                got = agx.forward_host(x, x, q, tw, pre, n, frames)
+                if not np.array_equal(got, want):
+                    errors.append((mine, rep))
+        except Exception as exc:      # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=((0, 1),)), threading.Thread(target=worker, args=((2, 3),))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert agx.lib().agx_ntt_release_caches() == 0          # and the caches can be dropped and rebuilt
+    q, tw, pre, x, want = cases[0]
+    assert np.array_equal(agx.forward_host(x, x, q, tw, pre, n, frames), want)
 
 
 def test_harness_binary_passes(agx):

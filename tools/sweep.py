@@ -20,13 +20,14 @@ ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--primes", type=int, default=4)
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--slabs", type=int, default=4)
+ap.add_argument("--bits", type=int, default=60, help="modulus size in bits")
 ap.add_argument("--op", choices=["fwd", "inv", "mul"], default="fwd")
 ap.add_argument("--launches", type=int, default=20, help="back-to-back launches per timing (20 = burst; 100+ shows the sustained clock)")
 ap.add_argument("--oop", action="store_true", help="time out of place (slab i -> slab i+1) instead of in place")
 args = ap.parse_args()
 N, P, B, SLABS = args.n, args.primes, args.batch, args.slabs
-ids = args.ids or [93, 90, 66]
-qs = agx.find_primes(60, N, P)
+ids = args.ids or [93]
+qs = agx.find_primes(args.bits, N, P)
 plan = agx.Plan(N, qs)
 stream = torch.cuda.current_stream().cuda_stream
 per = P * B * N
@@ -54,7 +55,7 @@ torch.cuda.synchronize()
 out = torch.empty_like(ref_in)
 ok = {}
 def select(k):
-    plan.set_variant(agx.VARIANT_LDS_RADIX2 if k < 0 else agx.VARIANT_REGBLOCK_BASE + k)
+    plan.set_variant(agx.VARIANT_AUTO if k == -2 else agx.VARIANT_LDS_RADIX2 if k < 0 else agx.VARIANT_REGBLOCK_BASE + k)      # -2: the plan's tuned default
 
 
 for k in ids:
