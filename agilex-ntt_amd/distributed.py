@@ -44,6 +44,20 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
 
+    def gather_rows(self, row):
+        """every rank's list of floats, in rank order (all ranks get the table): the per-rank timing / power / clock figures of
+        the benchmark, so that a slow or throttled rank is visible beside the MAX (None entries travel as NaN)"""
+        vals = [float("nan") if v is None else float(v) for v in row]
+        if not self.dist:
+            return [vals]
+        import torch
+
+        dev = self.device if self.device is not None else "cpu"
+        mine = torch.tensor(vals, dtype=torch.float64, device=dev)
+        table = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(table, mine)
+        return [[float(v) for v in t.cpu().tolist()] for t in table]
+
     def close(self):
         if self.dist:
             self.dist.destroy_process_group()

@@ -145,6 +145,10 @@ class PowerSampler:
                 "sclk_mhz_median": mhz[len(mhz) // 2] if mhz else None, "sclk_mhz_max_level": 2400,
                 "source": "amdgpu sysfs (hwmon power1_*, pp_dpm_sclk), 20 ms period, while the ramp + warm-up + timed steps ran"}
 
+    def median_w(self, t0, t1):
+        watts = sorted(s[1] for s in self.samples if t0 <= s[0] <= t1 and s[1] is not None)
+        return watts[len(watts) // 2] if watts else None
+
     def stop(self):
         self._stop.set()
         if self._thread:
@@ -168,36 +172,61 @@ def _timed(torch, fn, launches, warmup):
     return e0.elapsed_time(e1) / launches
 
 
-def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None):
+PROFILE_TAG = "r03b"      # the committed per-operation counter summaries the secondary lines point at
+
+
+def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None, idle_w=None):
     """The other north_star paths on the same clock, same process, after the headline:
     n=4096 inverse, n=4096 fused poly-mul, BASELINE configs[3] per-GPU slice (n=16384, 8 primes, batch 8192,
     in place) and configs[4] per-GPU slice (n=32768 poly-mul, batch 1024).  Each entry: units/s, average
     launch time (HIP events), algorithmic bytes per launch and the fraction of the 8 TB/s HBM roofline."""
     out = []
 
-    def entry(name, workload, units, bytes_per_unit, ms, unit, launches, note=None):
+    def entry(name, workload, units, bytes_per_unit, ms, unit, launches, note=None, profile=None):
         gbs = units * bytes_per_unit / (ms * 1e-3) / 1e9
         e = {"name": name, "workload": workload, "value": units / (ms * 1e-3), "unit": unit, "kernel_ms": ms,
              "launches_timed": launches, "algorithmic_bytes_per_launch": units * bytes_per_unit,
              "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
         if note:
             e["note"] = note
+        if profile:      # rocprofv3 counters of this line's dominant kernel(s): tools/profile_ops.sh -> tools/summarize_ops.py
+            e["profile"] = f"profiles/{PROFILE_TAG}_{profile}_summary.md"
         if sampler is not None:
             w = sampler.window(*_timed.window)
             if w:
                 e["power"] = {k: w[k] for k in ("samples", "socket_power_w_median", "sclk_mhz_median")}
+                if idle_w is not None and w["socket_power_w_median"] is not None:
+                    e["power"]["energy_uj_per_unit"] = (w["socket_power_w_median"] - idle_w) / (units / (ms * 1e-3)) * 1e6
         out.append(e)
 
     ns = len(slabs)
     units = NUM_PRIMES * batch
     # (1) n=4096 inverse, same slabs, in place (values are whatever the forward steps left: any input below 4q is legal)
     ms = _timed(torch, lambda i: plan4096.inverse(slabs[i % ns].data_ptr(), slabs[i % ns].data_ptr(), batch, stream), 300, 8)
-    entry("inverse_n4096", f"n={N_COEFF}, {NUM_PRIMES} primes, batch {batch}, inverse NTT in place", units, 16 * N_COEFF, ms, "NTT/s", 300)
+    entry("inverse_n4096", f"n={N_COEFF}, {NUM_PRIMES} primes, batch {batch}, inverse NTT in place", units, 16 * N_COEFF, ms, "NTT/s", 300, profile="inv4096")
     # (2) n=4096 fused polynomial product c = INTT(NTT(a) o NTT(b)), c aliasing a
     ms = _timed(torch, lambda i: plan4096.polymul(slabs[i % ns].data_ptr(), slabs[(i + 1) % ns].data_ptr(), slabs[i % ns].data_ptr(), 0, batch, stream), 120, 4)
     entry("polymul_n4096", f"n={N_COEFF}, {NUM_PRIMES} primes, batch {batch}, fused NTT x2 -> pointwise -> INTT in one launch (24n bytes per product)",
           units, 24 * N_COEFF, ms, "products/s", 120,
-          note="three transforms per 24n bytes: bounded by VALU integer multiply issue, not HBM (DESIGN.md section 4)")
+          note="three transforms per 24n bytes: bounded by VALU integer multiply issue, not HBM (DESIGN.md section 4)", profile="mul4096")
+
+    # narrow moduli (the reference's own modulus class: src/main.cpp:55 is 65537, BASELINE configs[0] a 30-bit prime): 32-bit arithmetic
+    # kernels, same uint64 data at the ABI, same 16n bytes per NTT -- the configuration where the engine is HBM-bound, not power-bound
+    for nn, tag in ((1024, "fwd1024q30"), (4096, "fwd4096q30")):
+        pn = agx.Plan(nn, agx.find_primes(30, nn, NUM_PRIMES))
+        per = NUM_PRIMES * batch * nn
+        views = [sl[:per] for sl in slabs]
+        for k, v in enumerate(views):
+            pn.fill_synthetic(v.data_ptr(), batch, k * batch, 42, stream)
+        ms = _timed(torch, lambda i: pn.forward(views[i % ns].data_ptr(), views[i % ns].data_ptr(), batch, stream), 300, 8)
+        entry(f"forward_n{nn}_30bit", f"n={nn}, {NUM_PRIMES} primes of 30 bits, batch {batch}, forward NTT in place, 32-bit arithmetic kernels (csrc/rb32_kernels.hpp)",
+              units, 16 * nn, ms, "NTT/s", 300, profile=tag)
+        if nn == 4096:
+            ms = _timed(torch, lambda i: pn.inverse(views[i % ns].data_ptr(), views[i % ns].data_ptr(), batch, stream), 300, 8)
+            entry("inverse_n4096_30bit", f"n={nn}, {NUM_PRIMES} primes of 30 bits, batch {batch}, inverse NTT in place, 32-bit arithmetic", units, 16 * nn, ms, "NTT/s", 300, profile="inv4096q30")
+            ms = _timed(torch, lambda i: pn.polymul(views[i % ns].data_ptr(), views[(i + 1) % ns].data_ptr(), views[i % ns].data_ptr(), 0, batch, stream), 200, 4)
+            entry("polymul_n4096_30bit", f"n={nn}, {NUM_PRIMES} primes of 30 bits, batch {batch}, fused product in one launch, 32-bit arithmetic", units, 24 * nn, ms, "products/s", 200, profile="mul4096q30")
+        pn.close()
     for s in slabs:
         s.untyped_storage().resize_(0)      # give the 2 GiB back before the large slices
     torch.cuda.empty_cache()
@@ -209,9 +238,9 @@ def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None):
     plan3.fill_synthetic(buf.data_ptr(), b3, 0, 42, stream)
     ms = _timed(torch, lambda i: plan3.forward(buf.data_ptr(), buf.data_ptr(), b3, stream), 16, 2)
     entry("forward_n16384_config4_slice", f"n={n3}, {p3} primes, batch {b3} per GPU (BASELINE.json configs[3] / 8 GPUs), forward in place, 8 GiB",
-          p3 * b3, 16 * n3, ms, "NTT/s", 16)
+          p3 * b3, 16 * n3, ms, "NTT/s", 16, profile="fwd16384")
     ms = _timed(torch, lambda i: plan3.inverse(buf.data_ptr(), buf.data_ptr(), b3, stream), 16, 2)
-    entry("inverse_n16384_config4_slice", f"n={n3}, {p3} primes, batch {b3} per GPU, inverse in place, 8 GiB", p3 * b3, 16 * n3, ms, "NTT/s", 16)
+    entry("inverse_n16384_config4_slice", f"n={n3}, {p3} primes, batch {b3} per GPU, inverse in place, 8 GiB", p3 * b3, 16 * n3, ms, "NTT/s", 16, profile="inv16384")
     plan3.close()
     del buf
     torch.cuda.empty_cache()
@@ -228,10 +257,12 @@ def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None):
     scratch = torch.empty(b4 * n4, dtype=torch.int64, device="cuda")
     ms = _timed(torch, lambda i: plan4.polymul(ab[i % sets][0].data_ptr(), ab[i % sets][1].data_ptr(), c.data_ptr(), scratch.data_ptr(), b4, stream), 120, 3)
     entry("polymul_n32768_config5_slice", f"n={n4}, one {PRIME_BITS}-bit prime, batch {b4} per GPU (BASELINE.json configs[4] / 8 GPUs), "
-          "c = INTT(NTT(a) o NTT(b)), operands never modified", b4, 24 * n4, ms, "products/s", 120,
-          note="VALU-bound like polymul_n4096")
+          "c = INTT(NTT(a) o NTT(b)) in one launch (one frame in registers, NTT(a) parked in c's frame), operands never modified", b4, 24 * n4, ms, "products/s", 120,
+          note="VALU-bound like polymul_n4096", profile="mul32768")
     ms = _timed(torch, lambda i: plan4.forward(ab[i % sets][0].data_ptr(), c.data_ptr(), b4, stream), 300, 3)
-    entry("forward_n32768", f"n={n4}, one prime, batch {b4}, forward out of place", b4, 16 * n4, ms, "NTT/s", 300)
+    entry("forward_n32768", f"n={n4}, one prime, batch {b4}, forward out of place", b4, 16 * n4, ms, "NTT/s", 300, profile="fwd32768oop")
+    ms = _timed(torch, lambda i: plan4.inverse(ab[i % sets][0].data_ptr(), c.data_ptr(), b4, stream), 300, 3)
+    entry("inverse_n32768", f"n={n4}, one prime, batch {b4}, inverse out of place", b4, 16 * n4, ms, "NTT/s", 300, profile="inv32768")
     plan4.close()
     return out
 
@@ -292,7 +323,11 @@ def main():
     # follow unchanged.  The first barrier here also pays RCCL's communicator set-up outside the timing.
     grp.barrier()
     torch.cuda.synchronize()
-    sampler = PowerSampler(torch, local_rank) if rank == 0 else None
+    sampler = PowerSampler(torch, local_rank)      # every rank samples its own GPU (per_rank below); rank 0's goes into `power`
+    # idle socket power: 0.4 s with nothing queued, before the ramp (the baseline of energy_uj_per_ntt)
+    t_idle0 = time.perf_counter()
+    time.sleep(0.4)
+    idle_w = sampler.median_w(t_idle0, time.perf_counter())
     t_busy0 = time.perf_counter() + 0.2     # skip the first 200 ms (idle -> ramp)
     ramp_steps = 0
     t_end = time.perf_counter() + args.ramp_seconds
@@ -316,17 +351,27 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0     # this rank's K steps; the slowest rank defines the job (MAX below)
     t_busy1 = time.perf_counter()
-    power = None
-    if sampler:
-        power = sampler.window(t_busy0, t_busy1)
+    power = sampler.window(t_busy0, t_busy1)
     grp.barrier()
     torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # average launch duration over the timed region
+    own_elapsed = elapsed
     elapsed = grp.max_over_ranks(elapsed)
+    # every rank's own figures in rank order, so a slow or throttled rank is visible beside the MAX that defines `value`
+    rows = grp.gather_rows([own_elapsed, kernel_ms, power["socket_power_w_median"] if power else None, power["sclk_mhz_median"] if power else None])
+    nan2none = lambda v: None if v != v else v
+    per_rank = [{"rank": r, "elapsed_s": row[0], "kernel_ms": row[1], "socket_power_w_median": nan2none(row[2]), "sclk_mhz_median": nan2none(row[3])}
+                for r, row in enumerate(rows)]
 
     ntts_per_step_per_gpu = NUM_PRIMES * batch
     value = agx.aggregate_throughput(ntts_per_step_per_gpu, args.steps, world, elapsed)
-    achieved = ntts_per_step_per_gpu * ALGO_BYTES_PER_NTT / (kernel_ms * 1e-3) / 1e9
+    # achieved = NTT/s x 16n per GPU -- follows from `value` (wall clock around the K steps, slowest rank); the HIP-event
+    # figure of this rank's launches is kept beside it as kernel_ms / achieved_from_kernel_events
+    achieved = value / world * ALGO_BYTES_PER_NTT / 1e9
+    achieved_events = ntts_per_step_per_gpu * ALGO_BYTES_PER_NTT / (kernel_ms * 1e-3) / 1e9
+    if power and idle_w is not None and power["socket_power_w_median"] is not None:
+        power["idle_w"] = idle_w
+        power["energy_uj_per_ntt"] = (power["socket_power_w_median"] - idle_w) / (value / world) * 1e6      # the line to optimise at the power cap
     # HBM bytes per launch from the PMC passes of tools/profile.sh (FETCH_SIZE x2 + WRITE_SIZE, separate runs,
     # MI355X_MICROARCH.md): a figure of the build it was profiled on, so it is only reported while the kernel
     # sources still hash to what that profile recorded; otherwise null (re-run tools/profile.sh)
@@ -357,15 +402,16 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kernel_ms,
+            "achieved_from_kernel_events": achieved_events, "frac_from_kernel_events": achieved_events / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": ntts_per_step_per_gpu * ALGO_BYTES_PER_NTT,
         },
+        "per_rank": per_rank,
     }
-    if power:
+    if power and rank == 0:
         out["power"] = power
     if world == 1 and not args.no_secondary:
-        out["secondary"] = secondary_lines(torch, agx, plan, slabs, batch, stream, sampler)
-    if sampler:
-        sampler.stop()
+        out["secondary"] = secondary_lines(torch, agx, plan, slabs, batch, stream, sampler, idle_w)
+    sampler.stop()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

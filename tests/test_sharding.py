@@ -32,8 +32,9 @@ grp.barrier()
 elapsed = grp.max_over_ranks(1.0 + grp.rank)              # slowest rank defines the step time
 count = grp.sum_over_ranks(hi - lo)
 value = agx.aggregate_throughput(5, 10, grp.world, elapsed)
+rows = grp.gather_rows([1.0 + grp.rank, 0.25 * (grp.rank + 1), None, 1800 + grp.rank])   # elapsed, kernel_ms, watts (unreadable), sclk
 if grp.rank == 0:
-    json.dump({"elapsed": elapsed, "count": count, "value": value, "world": grp.world, "range": [lo, hi]},
+    json.dump({"elapsed": elapsed, "count": count, "value": value, "world": grp.world, "range": [lo, hi], "rows": rows},
               open(os.path.join(os.environ["AGX_OUT"], "rank0.json"), "w"))
 grp.close()
 '''
@@ -74,6 +75,10 @@ def test_world_size_2_gloo(tmp_path, orc):
     assert meta["world"] == 2 and meta["count"] == 11 and meta["range"] == [0, 5]
     assert meta["elapsed"] == 2.0                       # MAX over ranks, not rank 0's own time
     assert meta["value"] == 5 * 10 * 2 / 2.0            # whole-job units / slowest rank's time
+    # the per-rank table bench.py prints as `per_rank`: one row per rank, in rank order, None carried as NaN
+    rows = meta["rows"]
+    assert len(rows) == 2 and [r[0] for r in rows] == [1.0, 2.0] and [r[1] for r in rows] == [0.25, 0.5] and [r[3] for r in rows] == [1800.0, 1801.0]
+    assert all(r[2] != r[2] for r in rows)
     # concatenating the ranks' blocks reproduces the single-process transform: nothing was exchanged
     n, primes, total = 256, 2, 11
     r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")

@@ -8,6 +8,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# the device sources these counters are measured on (summarize_profile.py copies this into profiles/hbm_traffic.json; bench.py
+# reports roofline.traffic only while the tree still hashes to it)
+python3 -c "import agilex_ntt_amd as a; print(a.kernel_source_sha16())" > "$OUT/kernel_source_sha16.txt"
 BENCH="python3 bench.py --steps 20 --warmup 3 --ramp-seconds 0.05 --no-cpu-baseline --no-secondary"
 # the stats pass runs bench.py's default step counts so its per-kernel average is the bench's own
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -- python3 bench.py --no-cpu-baseline --no-secondary > "$OUT/trace.log" 2>&1 || echo "trace pass failed" >> "$OUT/errors.txt"

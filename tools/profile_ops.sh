@@ -22,13 +22,13 @@ OPS[fwd32768oop]="--op fwd --n 32768 --primes 1 --batch 1024 --slabs 3 --oop"
 OPS[fwd32768ip]="--op fwd --n 32768 --primes 1 --batch 1024 --slabs 3"
 OPS[inv32768]="--op inv --n 32768 --primes 1 --batch 1024 --slabs 3"
 OPS[mul32768]="--op mul --n 32768 --primes 1 --batch 1024 --slabs 3"
-OPS[fwd1024q30]="--op fwd --n 1024 --primes 4 --batch 16384 --bits 30"
+OPS[fwd1024q30]="--op fwd --n 1024 --primes 4 --batch 4096 --bits 30"
 OPS[fwd4096q30]="--op fwd --n 4096 --primes 4 --batch 4096 --bits 30"
 OPS[inv4096q30]="--op inv --n 4096 --primes 4 --batch 4096 --bits 30"
 OPS[mul4096q30]="--op mul --n 4096 --primes 4 --batch 4096 --bits 30"
 
 LIST=("$@")
-if [ ${#LIST[@]} -eq 0 ]; then LIST=(inv4096 mul4096 fwd16384 inv16384 fwd32768oop fwd32768ip inv32768 mul32768); fi
+if [ ${#LIST[@]} -eq 0 ]; then LIST=(fwd4096 inv4096 mul4096 fwd16384 inv16384 fwd32768oop fwd32768ip inv32768 mul32768 fwd1024q30 fwd4096q30 inv4096q30 mul4096q30); fi
 
 for op in "${LIST[@]}"; do
   ARGS=${OPS[$op]:-}
