@@ -208,7 +208,9 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         const unsigned __int128 mu = ~(unsigned __int128)0 / q;  // = floor(2^128 / q) for odd q > 1
         c.mu_hi = (uint64_t)(mu >> 64);
         c.mu_lo = (uint64_t)mu;
-        if (q >= (1ull << 58)) {
+        if (q >= (1ull << 58) && q <= (1ull << 60)) {
+            // reduce_final_est (modarith.hpp) needs v < 16q <= 2^64: only the 16q-lazy kernels (arith level 2, q <= 2^60) call it, and
+            // the estimate is only ever set for moduli they accept, so a wider modulus can never reach that path with est != 0
             // float slightly below 2^32 / q (reduce_final_est): scaled down by 2^-20, then rounded toward zero
             float f = (float)(4294967296.0 / (double)q * (1.0 - 1.0 / 1048576.0));
             if ((double)f > 4294967296.0 / (double)q * (1.0 - 1.0 / 1048576.0)) f = std::nextafterf(f, 0.0f);

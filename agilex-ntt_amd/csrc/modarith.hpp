@@ -318,6 +318,8 @@ __device__ __forceinline__ uint64_t reduce_final_lazy16(uint64_t v, const bf_con
 // the estimate k' is floor(v/q) or one less (never above: the remainder stays non-negative) -- then v - k' q in [0,2q)
 // and one conditional subtract finishes: 3 conversions/multiplies + 2 integer multiplies + 1 subtract step instead of
 // four subtract steps.  Smaller moduli (top word too short for the estimate) take the four steps.
+// Contract with the host (agx_ntt.cpp build_plan): est_inv != 0 only for q in [2^58, 2^60], so v < 16q <= 2^64 holds wherever the
+// estimate path runs; the kernels that call this are the 16q-lazy ones (rb2_frame::EST requires LAZY16, legal for q <= 2^60 only).
 // USE_EST: 1 = the caller has checked k.est_inv != 0 (quotient estimate), 0 = it has checked it is 0 (four steps), -1 = decide here
 template <bool SEL, int USE_EST = -1>
 __device__ __forceinline__ uint64_t reduce_final_est(uint64_t v, const bf_consts& k, const final_consts& f, bool lazy_out) {

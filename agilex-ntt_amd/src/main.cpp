@@ -2,8 +2,10 @@
 // smoke driver (src/main.cpp:14-89 there) with real tables and known answers instead of
 // placeholders.  `make run` builds and runs it.
 //
-// Checks, for n = 1024 (30-bit q) and n = 4096 / 16384 (60-bit q):
-//   NTT(delta_0) = (1,...,1);  NTT(X)[bitrev(k)] = psi^(2k+1);  INTT(NTT(x)) = x on random x.
+// Checks, for n = 1024 (30-bit q), n = 4096 / 16384 / 32768 (60-bit q) and n = 16384 under the reference's own 17-bit modulus 65537:
+//   NTT(delta_0) = (1,...,1);  NTT(X)[bitrev(k)] = psi^(2k+1);  INTT(NTT(x)) = x on random x;
+// the reference's operand pairing with inData2 != inData (src/kernel/ntt.cpp:584-590); and the convolution theorem against the
+// schoolbook product mod X^n + 1 (n = 64 and 1024).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -66,11 +68,73 @@ static int run_case(uint32_t n, uint32_t bits) {
     return bad != 0;
 }
 
+// the reference's operand pairing (src/kernel/ntt.cpp:584-590): the lower half of every frame comes from inData, the upper half
+// from inData2.  Two DIFFERENT buffers, each holding garbage in the half that must not be read: the result must equal the
+// transform of the stitched frame (computed through agx::ntt on a host copy).
+static int run_pairing_case(uint32_t n, uint32_t bits) {
+    uint64_t q = 0, psi = 0;
+    if (agx_ntt_find_primes(bits, n, 1, &q) || agx_ntt_min_root(q, n, &psi)) return 1;
+    const unsigned numFrames = 2;
+    buffer<uint64_t> a(numFrames * n), b(numFrames * n), modulus(1, q), tw(n), pre(n), outData(numFrames * n, 0), stitched(numFrames * n);
+    if (agx_ntt_make_tables(q, psi, n, tw.data(), pre.data())) return 1;
+    uint64_t s = 0xabcdefu + n;
+    auto next = [&] { s = s * 6364136223846793005ull + 1442695040888963407ull; return (s >> 3) % q; };
+    for (unsigned f = 0; f < numFrames; ++f)
+        for (uint32_t i = 0; i < n; ++i) {
+            const bool lower = i < n / 2;
+            const uint64_t v = next();
+            stitched[f * n + i] = v;
+            a[f * n + i] = lower ? v : ~0ull;      // inData's upper half and inData2's lower half are never read
+            b[f * n + i] = lower ? ~0ull : v;
+        }
+    agx::queue qu;
+    agx::ntt_input_kernel(a, b, modulus, tw, pre, numFrames, qu);
+    agx::fwd_ntt_kernel<0>(qu);
+    agx::ntt_output_kernel(outData, numFrames, qu);
+    int rc = qu.wait();
+    if (!rc) rc = agx::ntt(stitched.data(), n, q, numFrames, psi);
+    if (rc) { std::printf("n=%u pairing: failed: %s\n", n, agx_ntt_strerror(rc)); return 1; }
+    int bad = 0;
+    for (size_t i = 0; i < stitched.size(); ++i) bad += outData[i] != stitched[i];
+    std::printf("n=%5u q=%llu in2 != in (lower half from inData, upper from inData2)  mismatches=%d  %s\n", n, (unsigned long long)q, bad, bad ? "FAIL" : "PASS");
+    return bad != 0;
+}
+
+// the convolution theorem against the definition: c = INTT(NTT(a) o NTT(b)) must be the schoolbook product of a and b in
+// Z_q[X]/(X^n + 1), computed here coefficient by coefficient (n = 64: 4,096 multiply-adds per polynomial)
+static int run_schoolbook_case(uint32_t n, uint32_t bits) {
+    uint64_t q = 0, psi = 0;
+    if (agx_ntt_find_primes(bits, n, 1, &q) || agx_ntt_min_root(q, n, &psi)) return 1;
+    std::vector<uint64_t> a(n), b(n), want(n, 0);
+    uint64_t s = 0x5eed5eedu + n + bits;
+    auto next = [&] { s = s * 6364136223846793005ull + 1442695040888963407ull; return (s >> 3) % q; };
+    for (uint32_t i = 0; i < n; ++i) { a[i] = next(); b[i] = next(); }
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint64_t p = mulmod(a[i], b[j], q);
+            const uint32_t k = (i + j) % n;
+            want[k] = (i + j < n) ? (want[k] + p) % q : (want[k] + q - p) % q;      // X^n = -1
+        }
+    std::vector<uint64_t> fa(a), fb(b);
+    int rc = agx::ntt(fa.data(), n, q, 1, psi);
+    if (!rc) rc = agx::ntt(fb.data(), n, q, 1, psi);
+    for (uint32_t i = 0; i < n; ++i) fa[i] = mulmod(fa[i], fb[i], q);
+    if (!rc) rc = agx::intt(fa.data(), n, q, 1, psi);
+    if (rc) { std::printf("n=%u schoolbook: failed: %s\n", n, agx_ntt_strerror(rc)); return 1; }
+    int bad = 0;
+    for (uint32_t i = 0; i < n; ++i) bad += fa[i] != want[i];
+    std::printf("n=%5u q=%llu INTT(NTT(a) o NTT(b)) vs schoolbook product mod X^n+1  mismatches=%d  %s\n", n, (unsigned long long)q, bad, bad ? "FAIL" : "PASS");
+    return bad != 0;
+}
+
 int main() {
     int ndev = 0;
     agx_ntt_device_count(&ndev);
     if (ndev == 0) { std::printf("no HIP device: the forward path needs an MI355X\n"); return 2; }
-    int fail = run_case(1024, 30) | run_case(4096, 60) | run_case(16384, 60) | run_case(32768, 60);
+    // 17 bits: the modulus class of the reference's own smoke driver (65537, src/main.cpp:55) -> the 32-bit arithmetic kernels
+    int fail = run_case(1024, 30) | run_case(4096, 60) | run_case(16384, 60) | run_case(32768, 60) | run_case(16384, 17);
+    fail |= run_pairing_case(1024, 30) | run_pairing_case(16384, 60);
+    fail |= run_schoolbook_case(64, 30) | run_schoolbook_case(64, 60) | run_schoolbook_case(1024, 30);
     std::printf(fail ? "HARNESS FAILED\n" : "HARNESS PASSED\n");
     return fail;
 }

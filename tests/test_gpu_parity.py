@@ -212,13 +212,15 @@ def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
     plan.close()
 
 
-@pytest.mark.parametrize("bits,config", [(60, None), (61, None), (62, None), (60, 93), (59, 93), (58, 93), (45, 93)])
-def test_extreme_coefficients(agx, orc, dev, bits, config):
+@pytest.mark.parametrize("n,bits,config", [(4096, 60, None), (4096, 61, None), (4096, 62, None), (4096, 60, 93), (4096, 59, 93), (4096, 58, 93), (4096, 45, 93),
+                                           (16384, 60, 117), (16384, 59, 117), (16384, 58, 117), (16384, 45, 117), (16384, 61, None), (16384, 62, None),
+                                           (32768, 60, 119), (32768, 59, 119), (32768, 58, 119), (32768, 45, 119), (32768, 61, None), (32768, 62, None),
+                                           (1024, 60, None), (2048, 60, None), (8192, 60, None)])
+def test_extreme_coefficients(agx, orc, dev, n, bits, config):
     """worst-case lazy ranges: all coefficients 4q-1 / q-1 / 0 under the largest 60-, 61- and
-    62-bit moduli (16q-lazy, fast and exact forms respectively); config 93 = the tail-free schedule whose outputs
-    reach 16q before the quotient-estimate reduction, at 60/59-bit moduli (estimate path; 59 bits = the smallest
-    top words it sees), at 58 and 45 bits (q < 2^58: the four-step fallback)"""
-    n = 4096
+    62-bit moduli (16q-lazy, fast and exact forms respectively); configs 93 / 117 / 119 = the kernels with the tail-free schedule
+    whose outputs reach 16q before the quotient-estimate reduction (n = 4096, 16384, 32768), at 60/59-bit moduli (estimate path;
+    59 bits = the smallest top words it sees), at 58 and 45 bits (q < 2^58: the four-step fallback)"""
     q = orc.find_prime(bits, n)
     psi = orc.min_root(q, n)
     tw, pre = orc.make_tables(q, psi, n)
@@ -1048,7 +1050,8 @@ def test_one_shot_calls_from_two_threads_with_different_tables(agx, orc):
 
 def test_harness_binary_passes(agx):
     """bin/ntt_harness (src/main.cpp: the reference-shaped ntt_input_kernel / fwd_ntt_kernel<0> / ntt_output_kernel mirror,
-    agx::ntt() / agx::intt(), structured known answers, schoolbook product) as a child process on the GPU"""
+    agx::ntt() / agx::intt(), structured known answers, inData2 != inData, schoolbook product at n = 64 / 1024, the reference's
+    17-bit modulus) as a child process on the GPU"""
     import subprocess
 
     exe = os.path.join(os.path.dirname(agx.LIB_PATH), "..", "bin", "ntt_harness")
@@ -1057,6 +1060,7 @@ def test_harness_binary_passes(agx):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "HARNESS PASSED" in r.stdout, r.stdout[-2000:]
+    assert r.stdout.count("in2 != in") == 2 and r.stdout.count("schoolbook") == 3 and "FAIL" not in r.stdout, r.stdout[-2000:]
 
 
 def test_randomised_shapes_against_oracle(agx, orc, dev):
