@@ -217,9 +217,9 @@ namespace {
 // every group of the registry, one per translation unit
 template <class F>
 void for_each_entry(F&& f) {
-    const rb_span groups[] = {rb_entries_n4096(), rb_entries_n1024(), rb_entries_n2048(), rb_entries_n8192(), rb_entries_r5(), rb_entries_q32(),
+    const rb_span groups[] = {rb_entries_n4096(), rb_entries_r5(), rb_entries_q32(),
 #ifdef AGX_DIAG
-                              rb_entries_n4096_ab(), rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_gen1(), rb_entries_diag(),
+                              rb_entries_n1024(), rb_entries_n2048(), rb_entries_n8192(), rb_entries_n4096_ab(), rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_gen1(), rb_entries_diag(),
 #endif
     };
     for (const rb_span& g : groups)
@@ -268,8 +268,9 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int 
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
         static const int kDefaults[] = {130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141,      // narrow moduli: 32-bit arithmetic (tier 2, then tier 1)
-                                        93, 92, 91, 63, 29, 30, 59, 31, 32, 64, 33, 34,                 // n = 1024 ... 8192: 16q-lazy, fast, exact
-                                        119, 117, 121, 120, 123, 122};                                  // n = 32768 / 16384: whole-frame R = 5 kernels
+                                        93, 92, 91,                                                      // n = 4096: R = 3, 8 waves/SIMD (16q-lazy, fast, exact)
+                                        150, 151, 152, 153, 154, 155, 156, 157, 158,                     // n = 1024 / 2048 / 8192: streamed single-frame kernels
+                                        119, 117, 121, 120, 123, 122};                                  // n = 32768 / 16384
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
             if (c && split_for(*c) >= 0 && legal(*c)) { e = c; break; }

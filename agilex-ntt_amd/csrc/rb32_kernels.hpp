@@ -226,36 +226,31 @@ struct rb32_frame {
     __device__ __forceinline__ void load_last_layout(uint32_t (&x)[C], const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2,
                                                      uint64_t mu, int64_t base, bool wide) const {
         const uint32_t wbase = (tid >> 6) << (6 + R), lane = tid & 63u;
-        if (wide) {
-            static_for<0, C / 2>([&](auto K) {
-                constexpr int k = K;
-                const uint32_t e = wbase + 2u * lane + 128u * (uint32_t)k;
-                const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(in + base + e));
-                uint32_t v0, v1;
-                if (in2) {   // wave-uniform
-                    const u64x2 u = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(in2 + base + e));
-                    const uint32_t p0 = a.mulmod(a.template enter<false>(v.x), a.template enter<false>(u.x), mu);
-                    const uint32_t p1 = a.mulmod(a.template enter<false>(v.y), a.template enter<false>(u.y), mu);
-                    v0 = p0;      // mulmod's range is the inverse's entry range
-                    v1 = p1;
-                } else {
-                    v0 = a.template enter<INVERSE>(v.x);
-                    v1 = a.template enter<INVERSE>(v.y);
-                }
-                const uint32_t s = img(e);
-                slab[s] = v0;
-                slab[s + 1] = v1;
-            });
-        } else {
+        if (in2) {      // wave-uniform; the product fused into the load (agx_ntt_polymul's fallback path): no priority games, one word at a time
+            __builtin_amdgcn_s_setprio(0);
             static_for<0, C>([&](auto Rr) {
                 constexpr int r = Rr;
                 const uint32_t e = wbase + lane + 64u * (uint32_t)r;
-                const uint64_t v = __builtin_nontemporal_load(&in[base + e]);
-                uint32_t w;
-                if (in2) w = a.mulmod(a.template enter<false>(v), a.template enter<false>(__builtin_nontemporal_load(&in2[base + e])), mu);
-                else w = a.template enter<INVERSE>(v);
-                slab[img(e)] = w;
+                slab[img(e)] = a.mulmod(a.template enter<false>(__builtin_nontemporal_load(&in[base + e])), a.template enter<false>(__builtin_nontemporal_load(&in2[base + e])), mu);
             });
+        } else if (wide) {
+            // every load is issued first (the kernels enter at raised priority), then the priority drops and the words are converted and staged
+            u64x2 v[C / 2];
+            static_for<0, C / 2>([&](auto K) { constexpr int k = K; v[k] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(in + base + wbase + 2u * lane + 128u * (uint32_t)k)); });
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_setprio(0);
+            static_for<0, C / 2>([&](auto K) {
+                constexpr int k = K;
+                const uint32_t s = img(wbase + 2u * lane + 128u * (uint32_t)k);
+                slab[s] = a.template enter<INVERSE>(v[k].x);
+                slab[s + 1] = a.template enter<INVERSE>(v[k].y);
+            });
+        } else {
+            uint64_t v[C];
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; v[r] = __builtin_nontemporal_load(&in[base + wbase + lane + 64u * (uint32_t)r]); });
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_setprio(0);
+            static_for<0, C>([&](auto Rr) { constexpr int r = Rr; slab[img(wbase + lane + 64u * (uint32_t)r)] = a.template enter<INVERSE>(v[r]); });
         }
         wave_lds_sync();
         const uint32_t own = img(tid << R);
@@ -285,8 +280,12 @@ template <int L, int R, int PPB, int TIER, int MINW>
 __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 fwd_q32(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const prime_consts* __restrict__ consts,
         const twpair* __restrict__ tw_rb, uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride, uint32_t flags) {
+    // a wave issues its frame loads at raised priority (new waves are the youngest on their SIMD and would otherwise queue behind
+    // seven older ones' butterflies before their first load goes out): +3 ... +8 % at every size (profiles/r03_q32_priority.txt)
+    __builtin_amdgcn_s_setprio(3);
     AGX_RB32_PROLOGUE;
     uint32_t x[C];
+    {
     static_for<0, C>([&](auto Rr) {
         constexpr int r = Rr;
         if constexpr (TIER == 2) {
@@ -296,6 +295,9 @@ fwd_q32(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, const prime
             x[r] = f.a.template enter<false>(__builtin_nontemporal_load(&in[base + f.tid + (uint32_t)r * T]));
         }
     });
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_setprio(0);
     f.forward(x, tbl, (flags & 1u) != 0);
     f.store_last_layout(x, out, base, live, wide);
 }
@@ -304,6 +306,7 @@ template <int L, int R, int PPB, int TIER, int MINW>
 __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 inv_q32(const uint64_t* __restrict__ in, const uint64_t* __restrict__ in2, uint64_t* __restrict__ out, const prime_consts* __restrict__ consts,
         const twpair* __restrict__ tw_rb, uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride, uint32_t flags) {
+    __builtin_amdgcn_s_setprio(3);      // until the frame loads are out (load_last_layout lowers it)
     AGX_RB32_PROLOGUE;      // tw_rb = the plan's inverse table here
     uint32_t x[C];
     f.template load_last_layout<true>(x, in, in2, pc.mu_hi, base, wide);
@@ -320,11 +323,18 @@ __global__ void __launch_bounds__((1 << (L - R)) * PPB, MINW)
 polymul_q32(const uint64_t* __restrict__ pa, const uint64_t* __restrict__ pb, uint64_t* __restrict__ pcout, const prime_consts* __restrict__ consts,
             const twpair* __restrict__ tw_rb, const twpair* __restrict__ itw_rb, uint32_t pairs_per_prime, uint64_t frames_x,
             int64_t prime_stride, int64_t poly_stride, uint32_t flags) {
+    __builtin_amdgcn_s_setprio(3);      // until a's loads are out
     AGX_RB32_PROLOGUE;
     (void)wide;
     const tw32* itbl = reinterpret_cast<const tw32*>(itw_rb) + (size_t)prime * pairs_per_prime * 2;
     uint32_t xa[C], xb[C];
-    static_for<0, C>([&](auto Rr) { constexpr int r = Rr; xa[r] = f.a.template enter<false>(__builtin_nontemporal_load(&pa[base + f.tid + (uint32_t)r * T])); });
+    {
+        uint64_t va[C];
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; va[r] = __builtin_nontemporal_load(&pa[base + f.tid + (uint32_t)r * T]); });
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        static_for<0, C>([&](auto Rr) { constexpr int r = Rr; xa[r] = f.a.template enter<false>(va[r]); });
+    }
     f.forward(xa, tbl, true);
     asm volatile("" ::: "memory");      // b's loads stay behind NTT(a)
     static_for<0, C>([&](auto Rr) { constexpr int r = Rr; xb[r] = f.a.template enter<false>(__builtin_nontemporal_load(&pb[base + f.tid + (uint32_t)r * T])); });

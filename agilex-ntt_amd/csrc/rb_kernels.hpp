@@ -2013,6 +2013,25 @@ constexpr rb_entry make_entry_single(int id) {
     return e;
 }
 
+// ... with the fused product by polymul_rb2 (both forward results in registers) at MULW waves per SIMD: small frames, where two
+// frames of 2^R coefficients still fit the register budget and the parked product's round trip through c's frame costs more
+template <int L, int R, int ARITH, int MINW, int MULW>
+hipError_t init_rb2_single_mul2_t() {
+    const int bytes = (int)rb2_lds_bytes<L, R, 1, ARITH>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_rb2<L, R, 1, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_rb2<L, R, 1, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polymul_rb2<L, R, 1, ARITH, MULW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e;
+}
+template <int L, int R, int ARITH, int MINW, int MULW>
+constexpr rb_entry make_entry_single_mul2(int id) {
+    rb_entry e = make_entry_single<L, R, ARITH, MINW>(id);
+    e.init = &init_rb2_single_mul2_t<L, R, ARITH, MINW, MULW>;
+    e.launch_mul = &launch_mul_rb2_t<L, R, 1, ARITH, MULW>;
+    e.mul_parked = false;
+    return e;
+}
+
 // ... with the forward (FWD) and / or inverse (INV) launches by the dynamic loop kernels (resident grid, ticket counter; captured
 // launches take the fixed-stride form)
 template <int L, int R, int ARITH, int MINW>

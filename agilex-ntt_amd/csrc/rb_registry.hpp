@@ -41,15 +41,15 @@ struct rb_span {
 
 // one group per translation unit, so the ~50 kernel instantiations compile in parallel
 // product groups (their A/B extras are compiled in under AGX_DIAG)
-rb_span rb_entries_n1024();
-rb_span rb_entries_n2048();
 rb_span rb_entries_n4096();
-rb_span rb_entries_n8192();
 rb_span rb_entries_r5();
 rb_span rb_entries_q32();
 #ifdef AGX_DIAG
 // groups that only exist in lib/libagxntt_diag.so: earlier generations and measured-and-rejected shapes, kept selectable for A/B runs
 rb_span rb_entries_gen1();
+rb_span rb_entries_n1024();      // the R = 3 kernels of n = 1024 / 2048 / 8192 (round-2 defaults, superseded by the streamed single-frame kernels)
+rb_span rb_entries_n2048();
+rb_span rb_entries_n8192();
 rb_span rb_entries_n4096_ab();
 rb_span rb_entries_n8192_split();
 rb_span rb_entries_n8192_pair();

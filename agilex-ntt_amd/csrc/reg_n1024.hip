@@ -10,12 +10,9 @@ const rb_entry kEntries[] = {
     make_entry2<10, 3, 4, 0 | (kOptPad << 1), 8>(30),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect) << 1), 8>(29),
     make_entry2<10, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(63),   // A/B: one frame per 128-thread workgroup
-#ifdef AGX_DIAG
-    // A/B entries (lib/libagxntt_diag.so only)
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(40),
     make_entry2<10, 3, 4, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(61),
     make_entry2<10, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(62),   // A/B: two frames per 256-thread workgroup
-#endif
 };
 }  // namespace AGX_TU
 

@@ -10,8 +10,6 @@ const rb_entry kEntries[] = {
     make_entry2<11, 3, 2, 0 | (kOptPad << 1), 8>(32),
     make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect) << 1), 8>(31),
     make_entry2<11, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(59),   // A/B: one frame per 256-thread workgroup (8 workgroups per CU)
-#ifdef AGX_DIAG
-    // A/B entries (lib/libagxntt_diag.so only)
     // A/B at n = 4096: one 256-thread workgroup per frame, its two 2048-halves in turn (4-wave barrier, 17 KiB image)
     make_entry_pair<11, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 6>(94),
     make_entry_pair<11, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 8>(95),
@@ -20,7 +18,6 @@ const rb_entry kEntries[] = {
     make_entry_split<11, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 8, 1>(97),
     make_entry_split<11, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtStore) << 1), 8, 1>(98),
     make_entry2<11, 3, 2, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(41),
-#endif
 };
 }  // namespace AGX_TU
 

@@ -10,11 +10,8 @@ const rb_entry kEntries[] = {
     make_entry2<13, 3, 1, 0 | (kOptPad << 1), 8>(34),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect) << 1), 8>(33),
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 8>(64),
-#ifdef AGX_DIAG
-    // A/B entries (lib/libagxntt_diag.so only)
     make_entry2<13, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16) << 1), 8>(42),
     make_entry2<13, 4, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptLazyInv | kOptNtLoad | kOptNtStore) << 1), 4>(65),   // A/B: R = 4, 512-thread workgroups (8 waves), 4 waves/SIMD
-#endif
 };
 }  // namespace AGX_TU
 

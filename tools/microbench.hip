@@ -19,9 +19,9 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
-enum Op { ADD32, MAD64, MAD64_SGPR, MULLO, MULHI, MAD24, MULHI24, LSHLADD64, ADDC_PAIR, CMP_CND64, FMA64, DPP_MOV, PERMSWAP, BPERMUTE, SUB_PAIR, MUL24_E32, ADD32_E64, ADD3, CNDMASK_E32, CMP64_ONLY, CMP32_ONLY, XOR_E32, MOV_E32, LSHL_ADD_U32, NOPS };
+enum Op { ADD32, MAD64, MAD64_SGPR, MULLO, MULHI, MAD24, MULHI24, LSHLADD64, ADDC_PAIR, CMP_CND64, FMA64, DPP_MOV, PERMSWAP, BPERMUTE, SUB_PAIR, MUL24_E32, ADD32_E64, ADD3, CNDMASK_E32, CMP64_ONLY, CMP32_ONLY, XOR_E32, MOV_E32, LSHL_ADD_U32, NOPS, MULHI_MIX, MULLO_MIX };
 static const char* op_name[] = {"v_add_u32", "v_mad_u64_u32", "v_mad_u64_u32(sgpr src)", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
-    "v_lshl_add_u64", "v_add_co+v_addc_co (pair)", "v_cmp_ge_u64+2cndmask (triple)", "v_fma_f64", "v_mov_b32 dpp quad_perm", "v_permlane32_swap", "ds_bpermute_b32", "v_sub_co+v_subb_co (pair)", "v_mul_u32_u24_e32 (VOP2)", "v_add_u32_e64 (VOP3)", "v_add3_u32", "v_cndmask_b32_e32 (vcc)", "v_cmp_ge_u64 only", "v_cmp_lt_i32 only", "v_xor_b32_e32", "v_mov_b32_e32", "v_lshl_add_u32"};
+    "v_lshl_add_u64", "v_add_co+v_addc_co (pair)", "v_cmp_ge_u64+2cndmask (triple)", "v_fma_f64", "v_mov_b32 dpp quad_perm", "v_permlane32_swap", "ds_bpermute_b32", "v_sub_co+v_subb_co (pair)", "v_mul_u32_u24_e32 (VOP2)", "v_add_u32_e64 (VOP3)", "v_add3_u32", "v_cndmask_b32_e32 (vcc)", "v_cmp_ge_u64 only", "v_cmp_lt_i32 only", "v_xor_b32_e32", "v_mov_b32_e32", "v_lshl_add_u32", "nops", "v_mul_hi_u32 + v_xor_b32 (operands stay random)", "v_mul_lo_u32 + v_xor_b32 (operands stay random)"};
 
 // 8 independent chains per asm block, 2 blocks per loop iteration = 16 "units" per iteration
 template <int OP>
@@ -55,6 +55,15 @@ __global__ void __launch_bounds__(256) alu_kernel(uint64_t* out, int iters, uint
                 asm volatile("v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n"
                              "v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8\n"
                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b));
+            } else if constexpr (OP == MULHI_MIX || OP == MULLO_MIX) {
+                // x <- mul(x, b) ^ a: the xor with a per-lane random word keeps the multiplier's operands full-width and changing (a bare
+                // x <- mul_hi(x, b) chain decays to zero within a few steps and measures a multiplier that toggles nothing)
+#define AGX_MIX(OPC) asm volatile(OPC " %0, %0, %8\n v_xor_b32 %0, %0, %9\n " OPC " %1, %1, %8\n v_xor_b32 %1, %1, %9\n " OPC " %2, %2, %8\n v_xor_b32 %2, %2, %9\n " OPC " %3, %3, %8\n v_xor_b32 %3, %3, %9\n" \
+                             OPC " %4, %4, %8\n v_xor_b32 %4, %4, %9\n " OPC " %5, %5, %8\n v_xor_b32 %5, %5, %9\n " OPC " %6, %6, %8\n v_xor_b32 %6, %6, %9\n " OPC " %7, %7, %8\n v_xor_b32 %7, %7, %9\n" \
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b), "v"(a))
+                if constexpr (OP == MULHI_MIX) AGX_MIX("v_mul_hi_u32");
+                else AGX_MIX("v_mul_lo_u32");
+#undef AGX_MIX
             } else if constexpr (OP == MAD24) {
                 asm volatile("v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n"
                              "v_mad_u32_u24 %4, %4, %8, %9\n v_mad_u32_u24 %5, %5, %8, %9\n v_mad_u32_u24 %6, %6, %8, %9\n v_mad_u32_u24 %7, %7, %8, %9\n"
@@ -461,7 +470,10 @@ static void run_power() {
     const double lane_ops = (double)blocks * 256 * iters * 16;
     power_phase(probe, "v_add_u32 loop, 8 waves/SIMD", [&] { alu_kernel<ADD32><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
     power_phase(probe, "v_mad_u64_u32 loop, 8 waves/SIMD", [&] { alu_kernel<MAD64><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
-    power_phase(probe, "v_mul_hi_u32 loop, 8 waves/SIMD", [&] { alu_kernel<MULHI><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
+    power_phase(probe, "v_xor_b32 loop, 8 waves/SIMD", [&] { alu_kernel<XOR_E32><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
+    power_phase(probe, "v_mul_hi_u32 + v_xor_b32 (random operands), 8 waves/SIMD", [&] { alu_kernel<MULHI_MIX><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G pairs/s");
+    power_phase(probe, "v_mul_lo_u32 + v_xor_b32 (random operands), 8 waves/SIMD", [&] { alu_kernel<MULLO_MIX><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G pairs/s");
+    power_phase(probe, "v_mul_hi_u32 x <- hi(x b) chain (DECAYS TO ZERO operands: not a multiplier figure)", [&] { alu_kernel<MULHI><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
     power_phase(probe, "v_lshl_add_u64 loop, 8 waves/SIMD", [&] { alu_kernel<LSHLADD64><<<blocks, 256>>>(d_out, iters, 12345u); }, lane_ops, "G lane-ops/s");
     power_phase(probe, "v_mad_u64_u32 loop, 2 waves/SIMD", [&] { alu_kernel<MAD64><<<256 * 2, 256>>>(d_out, iters, 12345u); }, lane_ops / 4, "G lane-ops/s");
     CK(hipFree(d_out));
