@@ -40,6 +40,8 @@ struct agx_ntt_plan {
     ulonglong2* d_tw_rb = nullptr;
     ulonglong2* d_itw_rb = nullptr;
     regblock_layout rb;
+    regblock_layout rb_fwd;            // forward-only layout (another kernel shape that is faster for the forward transform), or invalid
+    ulonglong2* d_tw_rb_fwd = nullptr;
     // {next frame, retired workgroups} pairs for the kernels that hand out frames dynamically (the loop kernels of n >= 16384; diag
     // ids 83/84), one pair per STREAM: launches on one stream run one after the other, and the last workgroup of a launch zeroes the
     // pair, so a stream's launches can share one; launches on different streams get different pairs.  Only a launcher that needs a
@@ -135,6 +137,7 @@ void free_plan(agx_ntt_plan* p) {
     if (p->d_itw) (void)hipFree(p->d_itw);
     if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
     if (p->d_itw_rb) (void)hipFree(p->d_itw_rb);
+    if (p->d_tw_rb_fwd) (void)hipFree(p->d_tw_rb_fwd);
     delete p;
 }
 
@@ -199,7 +202,8 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
         if (moduli[k] >= (1ull << 31)) p->narrow_level = 0;
     }
     p->rb = regblock_choose(n, -1, p->arith_level, p->narrow_level);
-    std::vector<ulonglong2> rb_pairs, irb_pairs;
+    p->rb_fwd = regblock_forward_companion(p->rb, n, p->arith_level, p->narrow_level);
+    std::vector<ulonglong2> rb_pairs, irb_pairs, fwd_pairs;
     for (uint32_t k = 0; k < num_primes; ++k) {
         const uint64_t q = moduli[k];
         prime_consts& c = consts[k];
@@ -232,6 +236,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
             if (p->rb.valid()) regblock_build_table(p->rb, itwk, iprek, irb_pairs);
         }
         if (p->rb.valid()) regblock_build_table(p->rb, twk, prek, rb_pairs);
+        if (p->rb_fwd.valid()) regblock_build_table(p->rb_fwd, twk, prek, fwd_pairs);
     }
     if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
     {
@@ -243,6 +248,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     if (itw && (rc = upload(&p->d_itw, itw_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && (rc = upload(&p->d_tw_rb, rb_pairs)) != AGX_OK) { free_plan(p); return rc; }
     if (p->rb.valid() && itw && (rc = upload(&p->d_itw_rb, irb_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (p->rb_fwd.valid() && (rc = upload(&p->d_tw_rb_fwd, fwd_pairs)) != AGX_OK) { free_plan(p); return rc; }
     *out = p;
     return AGX_OK;
 }
@@ -459,6 +465,8 @@ static int plan_set_variant_impl(agx_ntt_plan* plan, int variant) {
             plan->rb = rb;
         }
     }
+    if (config_id >= 0 || variant == AGX_VARIANT_LDS_RADIX2) plan->rb_fwd = regblock_layout{};      // an explicit kernel choice applies to every call
+    else if (plan->d_tw_rb_fwd) plan->rb_fwd = regblock_forward_companion(plan->rb, plan->n, plan->arith_level, plan->narrow_level);
     plan->variant = variant;
     return AGX_OK;
 }
@@ -489,6 +497,10 @@ static int forward_common(const agx_ntt_plan* plan, const uint64_t* d_in, uint64
     fl.lazy_out = lazy_out;
     plan_view pv = view_of(plan);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (use_regblock(plan) && plan->rb_fwd.valid()) {      // the forward-only companion of the tuned default (n = 4096: +2.3 %)
+        pv.rb = plan->rb_fwd;
+        pv.tw_rb = plan->d_tw_rb_fwd;
+    }
     AGX_HIP(use_regblock(plan) ? launch_forward_regblock(pv, d_in, d_out, fl, s) : launch_forward_radix2(pv, d_in, d_out, fl, s));
     return AGX_OK;
 }

@@ -56,6 +56,9 @@ struct frame_layout {
 // narrow_level: 0 some modulus >= 2^31; 1 every modulus < 2^31; 2 every modulus < 2^30 (the 32-bit kernels of rb32_kernels.hpp; they
 // also need arith_level >= 1, i.e. tables that honour the precon contract)
 regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int narrow_level = 0);
+// forward-only layout that serves the forward calls of a plan whose tuned default is `main` (a second kernel shape that is faster for
+// the forward transform only), or an invalid layout
+regblock_layout regblock_forward_companion(const regblock_layout& main, uint32_t n, int arith_level, int narrow_level);
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out);
 
 hipError_t kernels_init();  // one-time function attributes (large dynamic LDS)

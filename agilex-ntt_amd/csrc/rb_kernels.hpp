@@ -550,6 +550,7 @@ struct rb2_frame {
                     image_write<p>(x);
                     exchange_sync<p>();
                 }
+                if constexpr (PRIO_BARRIER && !G::exchange_is_wave_local(p)) __builtin_amdgcn_s_setprio(0);
                 hooks.template after_exchange_sync<p>();
             }
         });
@@ -2010,6 +2011,14 @@ constexpr rb_entry make_entry_single(int id) {
                &launch_inv_rb2_t<L, R, 1, ARITH, MINW>, &launch_mul_park_t<L, R, ARITH, MINW>, 0, nullptr, false};
     e.mul_parked = true;
     e.whole_only = true;       // the streamed inverse folds n^-1 into its top stage
+    return e;
+}
+
+// forward kernel only of a streamed single-frame shape (a plan's forward companion: rb_entry::fwd_companion)
+template <int L, int R, int ARITH, int MINW>
+constexpr rb_entry make_entry_single_fwd(int id) {
+    rb_entry e = make_entry_fwd_only<L, R, 1, ARITH, MINW>(id);
+    e.whole_only = true;
     return e;
 }
 

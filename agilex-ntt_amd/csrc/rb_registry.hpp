@@ -31,6 +31,7 @@ struct rb_entry {
     hipError_t (*launch_inv_loop)(const plan_view&, const uint64_t*, const uint64_t*, uint64_t*, const frame_layout&, hipStream_t) = nullptr;
     bool mul_parked = false;   // launch_mul keeps one frame in registers (the other parked in c's frame): legal at every log_local
     bool whole_only = false;   // the kernels assume the whole frame is resident (log_split = 0): never serves n = 2^(log_local + k)
+    int fwd_companion = 0;     // registry id of a forward-only entry that serves forward calls of a plan whose main entry is this one (0: none)
     int narrow = 0;            // 0: 64-bit arithmetic; 1: 32-bit arithmetic, every modulus < 2^31; 2: every modulus < 2^30 (rb32_kernels.hpp)
 };
 

@@ -35,6 +35,10 @@ const rb_entry kEntries[] = {
     make_entry_single<13, 5, kLazy, 4>(156),
     make_entry_single<13, 5, kFast, 4>(157),
     make_entry_single<13, 5, kExact, 4>(158),
+    // n = 4096, FORWARD ONLY: 128 threads x 32 coefficients, frame loads at raised priority; the forward companion of the R = 3 default (id 93):
+    // 59.5 vs 58.2 M NTT/s, 18.5 vs 18.9 uJ per NTT at the same 1400 W (profiles/r03_energy_ab.txt); its inverse (-1 %) and parked
+    // product (-4 %) lose to id 93's, so only the forward kernel ships (A/B twin with all three transforms: id 147)
+    make_entry_single_fwd<12, 5, kLazy | (kOptPrio << 1), 4>(159),
     // n = 16384 / 32768: forward one workgroup per frame, inverse by the ticket-drawing loop kernel (+3 % / +9 % at 8,192 frames of n = 32768)
     make_entry_single_dloop<14, 5, kLazy, 4, false, true>(117),
     make_entry_single_dloop<15, 5, kLazy, 4, false, true>(119),
@@ -53,6 +57,8 @@ const rb_entry kEntries[] = {
     make_entry_single<15, 5, kLazy | (kOptPrio << 1), 4>(125),
     // A/B: n = 4096 as 128 threads x 32 coefficients (+1 % over id 93); n = 1024 with the parked product (129) and at six waves per SIMD (149)
     make_entry_single<12, 5, kLazy, 4>(127),
+    make_entry_single<12, 5, kLazy | (kOptPrio << 1), 4>(147),
+    make_entry_single<12, 5, kLazy | ((kOptPrio | kOptPrioBarrier) << 1), 4>(148),
     make_entry_single<10, 4, kLazy, 5>(129),
     make_entry_single<10, 4, kLazy, 6>(149),
 #endif
