@@ -63,9 +63,10 @@ class AgxError(RuntimeError):
         super().__init__(f"{where}: agx status {status} ({msg}), hip error {lib().agx_ntt_last_hip_error()}")
 
 
-def build(verbose=False):
-    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", _HERE, f"-j{min(8, os.cpu_count() or 1)}", "build"]
+def build(verbose=False, with_diag=False):
+    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU).  with_diag: lib/libagxntt_diag.so in the same make
+    invocation, so the objects of both libraries compile side by side."""
+    cmd = ["make", "-C", _HERE, f"-j{min(8, os.cpu_count() or 1)}", "build"] + (["diag"] if with_diag else [])
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
@@ -127,7 +128,7 @@ def kernel_source_sha16():
     import hashlib
 
     h = hashlib.sha256()
-    files = glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + [os.path.join(_HERE, "csrc", f) for f in ("rb_kernels.hpp", "rb32_kernels.hpp", "rb_registry.hpp", "modarith.hpp", "ntt_kernels.hpp")]
+    files = glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + [os.path.join(_HERE, "csrc", f) for f in ("rb_kernels.hpp", "rb32_kernels.hpp", "rb_stream_opts.hpp", "rb_registry.hpp", "modarith.hpp", "ntt_kernels.hpp")]
     for f in sorted(files):
         h.update(os.path.relpath(f, _HERE).encode())
         h.update(open(f, "rb").read())

@@ -217,7 +217,8 @@ namespace {
 // every group of the registry, one per translation unit
 template <class F>
 void for_each_entry(F&& f) {
-    const rb_span groups[] = {rb_entries_n4096(), rb_entries_r5(), rb_entries_q32(),
+    const rb_span groups[] = {rb_entries_n4096(), rb_entries_s1024(), rb_entries_s2048(), rb_entries_s4096(), rb_entries_s8192(), rb_entries_s16384(), rb_entries_s32768(),
+                              rb_entries_q32a(), rb_entries_q32b(),
 #ifdef AGX_DIAG
                               rb_entries_n1024(), rb_entries_n2048(), rb_entries_n8192(), rb_entries_n4096_ab(), rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_gen1(), rb_entries_diag(),
 #endif

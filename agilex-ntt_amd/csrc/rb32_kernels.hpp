@@ -9,7 +9,7 @@
 // Fully reduced outputs are unique, so the results are bit-identical to the 64-bit kernels'.
 //   TIER 2 (every q < 2^30): the reference's value ranges, coefficients in [0,4q) between stages (ntt.cpp:331-369), 4q <= 2^32.
 //   TIER 1 (every q < 2^31): coefficients fully reduced after every butterfly (2q <= 2^32 is all the headroom there is).
-// Included by reg_q32.hip behind rb_kernels.hpp (geometry, static_for, wave_lds_sync, the dynamic LDS symbol).
+// Included by reg_q32a.hip / reg_q32b.hip behind rb_kernels.hpp (geometry, static_for, wave_lds_sync, the dynamic LDS symbol).
 #pragma once
 
 namespace agx {

@@ -43,8 +43,14 @@ struct rb_span {
 // one group per translation unit, so the ~50 kernel instantiations compile in parallel
 // product groups (their A/B extras are compiled in under AGX_DIAG)
 rb_span rb_entries_n4096();
-rb_span rb_entries_r5();
-rb_span rb_entries_q32();
+rb_span rb_entries_s1024();      // the streamed single-frame kernels, one group (translation unit) per size
+rb_span rb_entries_s2048();
+rb_span rb_entries_s4096();
+rb_span rb_entries_s8192();
+rb_span rb_entries_s16384();
+rb_span rb_entries_s32768();
+rb_span rb_entries_q32a();       // 32-bit arithmetic, tier 2 (every modulus < 2^30) / tier 1 (< 2^31)
+rb_span rb_entries_q32b();
 #ifdef AGX_DIAG
 // groups that only exist in lib/libagxntt_diag.so: earlier generations and measured-and-rejected shapes, kept selectable for A/B runs
 rb_span rb_entries_gen1();

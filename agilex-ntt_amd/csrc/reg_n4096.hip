@@ -12,7 +12,7 @@ constexpr rb_entry with_fwd_companion(rb_entry e, int id) {
     return e;
 }
 const rb_entry kEntries[] = {
-    with_fwd_companion(make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8>(93), 159),      // forward calls go to the streamed 128-thread kernel of reg_r5.hip (+2.3 %)   // 90 + tail-free subtract schedule and quotient-estimate final reduction
+    with_fwd_companion(make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8>(93), 159),      // forward calls go to the streamed 128-thread kernel of reg_s4096.hip (+2.3 %)   // 90 + tail-free subtract schedule and quotient-estimate final reduction
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
 #ifdef AGX_DIAG

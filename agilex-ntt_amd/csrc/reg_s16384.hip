@@ -1,0 +1,25 @@
+// reg_s16384.hip -- one size of the streamed single-frame kernels (the family is described at the top of reg_s1024.hip); a group of the kernel
+// registry (rb_registry.hpp): ids are stable handles for tests and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices.
+#define AGX_TU tu_s16384
+#include "rb_kernels.hpp"
+#include "rb_stream_opts.hpp"
+
+namespace agx {
+namespace AGX_TU {
+const rb_entry kEntries[] = {
+    // n = 16384: 512 threads, two workgroups per CU; forward one workgroup per frame, inverse by the ticket-drawing loop kernel (+3 %)
+    make_entry_single_dloop<14, 5, kLazy, 4, false, true>(117),
+    make_entry_single<14, 5, kFast, 4>(120),
+    make_entry_single<14, 5, kExact, 4>(122),
+#ifdef AGX_DIAG
+    // A/B: inverse one workgroup per frame too (115); forward by the loop kernel as well (118: 24 B of scratch, -3 %); 124 frame loads at raised priority (nothing)
+    make_entry_single<14, 5, kLazy, 4>(115),
+    make_entry_single_dloop<14, 5, kLazy, 4, true, true>(118),
+    make_entry_single<14, 5, kLazy | (kOptPrio << 1), 4>(124),
+#endif
+};
+}  // namespace AGX_TU
+
+rb_span rb_entries_s16384() { return rb_span{AGX_TU::kEntries, sizeof(AGX_TU::kEntries) / sizeof(AGX_TU::kEntries[0])}; }
+
+}  // namespace agx
