@@ -102,9 +102,10 @@ struct rb32_frame {
     using G = rb2_geom<L, R>;
     static constexpr int C = G::C, T = G::T, NP = G::NP;
     static_assert(T >= 64, "one frame spans whole waves");
-    static constexpr uint32_t slab_words = (1u << L) + (1u << (L - 4));
-    // image word of coefficient e: one pad word per 16 (additive over disjoint bit fields: thread base + compile-time constant)
-    static __device__ __forceinline__ constexpr uint32_t img(uint32_t e) { return e + (e >> 4); }
+    static constexpr uint32_t slab_words = (1u << L) + (1u << (L - 5));
+    // image word of coefficient e: one pad word per 32 (additive over disjoint bit fields: thread base + compile-time constant); of the
+    // shifts 3..7 this one leaves the fewest bank conflicts for 32-bit accesses (32 banks per group of 32 lanes) at every (L, R) used here
+    static __device__ __forceinline__ constexpr uint32_t img(uint32_t e) { return e + (e >> 5); }
     uint32_t tid;
     uint32_t* slab;
     q32_arith<TIER> a;
@@ -382,7 +383,7 @@ void build_table32_t(const regblock_layout&, const uint64_t* tw, const uint64_t*
 }
 
 template <int L, int R, int PPB>
-constexpr size_t q32_lds_bytes() { return (size_t)((1u << L) + (1u << (L - 4))) * 4 * PPB; }
+constexpr size_t q32_lds_bytes() { return (size_t)((1u << L) + (1u << (L - 5))) * 4 * PPB; }
 
 inline uint32_t q32_flags(const void* a, const void* b, const void* c, const frame_layout& fl) {
     const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15u) == 0 && ((fl.prime_stride | fl.poly_stride) & 1) == 0;

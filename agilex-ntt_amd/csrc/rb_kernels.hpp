@@ -314,11 +314,15 @@ struct rb2_frame {
     }
     // a per-lane pass with all R stages: the shape the look-ahead twiddle fetch handles
     static constexpr bool lane_full_pass(int p) { return p >= 0 && p < NP && G::rlo(p) < 6 && G::hi(p) - G::rlo(p) + 1 == R; }
-    static constexpr uint32_t slab_elems = PAD ? (1u << L) + (1u << (L - 4)) : (1u << L);
+    // pad: one image word per 16 coefficients for the 64-bit image (ds_read_b64: 64 banks), one per 32 for the split-word image, whose
+    // 32-bit accesses see 32 banks per group of 32 lanes: with it every exchange pattern of the R = 5 kernels is conflict-free, with one
+    // per 16 every one of them was two-way conflicted (SQ_LDS_BANK_CONFLICT 45 % of the LDS cycles, profiles/r03c_fwd4096_summary.md)
+    static constexpr int PADS = (OPT & kOptSplitWord) != 0 ? 5 : 4;
+    static constexpr uint32_t slab_elems = PAD ? (1u << L) + (1u << (L - PADS)) : (1u << L);
     static constexpr uint32_t image_bytes = slab_elems * (((OPT & kOptSplitWord) != 0) ? 4u : 8u);   // one frame's LDS image
     // image word of coefficient e; both forms are additive over disjoint bit fields, which is what
     // lets an exchange address register r as (thread base) combined with a compile-time constant
-    static __device__ __forceinline__ constexpr uint32_t img(uint32_t e) { return PAD ? e + (e >> 4) : lds_swz(e); }
+    static __device__ __forceinline__ constexpr uint32_t img(uint32_t e) { return PAD ? e + (e >> PADS) : lds_swz(e); }
     static __device__ __forceinline__ constexpr uint32_t join(uint32_t base, uint32_t delta) { return PAD ? base + delta : base ^ delta; }
     uint32_t tid, blk, split_log;
     bool lazy_out = false;   // forward only: leave results in [0,4q) (wave-uniform)
