@@ -166,6 +166,7 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
     p->log_n = (uint32_t)log2u(n);
     p->num_primes = num_primes;
     p->has_inverse = itw != nullptr;
+    p->ticket_streams.reserve(kTicketSlots);      // plan_ticket_for() runs inside unguarded launch calls: it must never allocate
     p->moduli.assign(moduli, moduli + num_primes);
     p->psi.assign(num_primes, 0);
     if (psi) p->psi.assign(psi, psi + num_primes);
