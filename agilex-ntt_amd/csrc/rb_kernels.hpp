@@ -253,6 +253,7 @@ constexpr int kOptPinBf = 1 << 26;         // with kOptStreamTw: butterflies are
                                            // the 128 a 1024-thread workgroup may use; one wave cannot issue faster than one VALU per ~8 clocks anyway (ILP buys nothing there)
 constexpr int kOptSaddrTw = 1 << 27;       // per-lane table entries addressed as wave-uniform base (SGPRs) + 32-bit lane index (always on with kOptStreamTw)
 constexpr int kOptFinalMode = 1 << 28;     // the last stage branches once per stage on the final-reduction mode instead of once per coefficient (always on with kOptStreamTw)
+constexpr int kOptStreamCh1 = 1 << 29;     // with kOptStreamTw: one table entry per chunk instead of two (8 fewer VGPRs: what the loop kernels need to stay out of scratch)
 constexpr int kOptTrace = 64;    // diagnostics (tools/timeline.py): every wave records s_memtime at 12 phase boundaries
 
 // where the kOptTrace kernels write: [wave][16] words, set through agx_ntt_debug_set_trace_buffer
@@ -490,7 +491,7 @@ struct rb2_frame {
     // ---- streamed twiddles (STREAM_TW) -------------------------------------------------------------------------------
     // A pass of ns stages reads, at its stage S, the 2^kk table entries j = 2^kk + o (kk = R - ns + S, o = b >> rb for butterfly b):
     // they are taken in chunks of up to CH entries, in stage order; chunk q+1 is requested before chunk q's butterflies run.
-    static constexpr int CH = R >= 5 ? 2 : 4;      // R = 5: two entries (8 VGPRs per buffer) keep the pass inside 128 VGPRs
+    static constexpr int CH = (OPT & kOptStreamCh1) != 0 ? 1 : R >= 5 ? 2 : 4;      // R = 5: two entries (8 VGPRs per buffer) keep the pass inside 128 VGPRs
     // forward: stage S of a pass has kk = R - ns + S (1, 2, 4 ... entries); inverse (INV): stages run the other way, kk = R - 1 - S
     static constexpr int st_kk(int ns, int S, bool inv = false) { return inv ? R - 1 - S : R - ns + S; }
     static constexpr int st_chunks_in_stage(int ns, int S, bool inv = false) { return (1 << st_kk(ns, S, inv)) > CH ? (1 << st_kk(ns, S, inv)) / CH : 1; }

@@ -16,6 +16,9 @@ const rb_entry kEntries[] = {
     make_entry_single<14, 5, kLazy, 4>(115),
     make_entry_single_dloop<14, 5, kLazy, 4, true, true>(118),
     make_entry_single<14, 5, kLazy | (kOptPrio << 1), 4>(124),
+    // A/B: forward by the ticket loop with one table entry per chunk (120 VGPRs, no scratch): still -4 % (n = 16384) / -3..-5 % (n = 32768) against one
+    // workgroup per frame -- the hand-over barrier and the thinner twiddle prefetch cost more than the overlapped store tail wins
+    make_entry_single_dloop<14, 5, kLazy | (kOptStreamCh1 << 1), 4, true, true>(145),
 #endif
 };
 }  // namespace AGX_TU

@@ -16,6 +16,9 @@ const rb_entry kEntries[] = {
     make_entry_single<15, 5, kLazy, 4>(114),
     make_entry_single_dloop<15, 5, kLazy, 4, true, true>(116),
     make_entry_single<15, 5, kLazy | (kOptPrio << 1), 4>(125),
+    // A/B: forward by the ticket loop with one table entry per chunk (120 VGPRs, no scratch): still -4 % (n = 16384) / -3..-5 % (n = 32768) against one
+    // workgroup per frame -- the hand-over barrier and the thinner twiddle prefetch cost more than the overlapped store tail wins
+    make_entry_single_dloop<15, 5, kLazy | (kOptStreamCh1 << 1), 4, true, true>(146),
 #endif
 };
 }  // namespace AGX_TU
