@@ -2019,6 +2019,12 @@ constexpr rb_entry make_entry_single(int id) {
     return e;
 }
 
+// entry e with forward calls of its plans routed to the forward-only entry `id` (rb_entry::fwd_companion)
+constexpr rb_entry with_fwd_companion(rb_entry e, int id) {
+    e.fwd_companion = id;
+    return e;
+}
+
 // forward kernel only of a streamed single-frame shape (a plan's forward companion: rb_entry::fwd_companion)
 template <int L, int R, int ARITH, int MINW>
 constexpr rb_entry make_entry_single_fwd(int id) {

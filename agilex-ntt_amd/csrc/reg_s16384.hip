@@ -8,7 +8,11 @@ namespace agx {
 namespace AGX_TU {
 const rb_entry kEntries[] = {
     // n = 16384: 512 threads, two workgroups per CU; forward one workgroup per frame, inverse by the ticket-drawing loop kernel (+3 %)
-    make_entry_single_dloop<14, 5, kLazy, 4, false, true>(117),
+    with_fwd_companion(make_entry_single_dloop<14, 5, kLazy, 4, false, true>(117), 164),
+    // FORWARD ONLY, the forward companion of 117: R = 4 (16 coefficients per thread) with one table entry per chunk fits 63 VGPRs, so two
+    // 1024-thread workgroups per CU run at 8 waves/SIMD: +2.3 % forward (42.75 vs 41.79 % of 8 TB/s); its inverse and product only equal 117's
+    // (A/B twin with all three transforms: id 160)
+    make_entry_single_fwd<14, 4, kLazy | (kOptStreamCh1 << 1), 8>(164),
     make_entry_single<14, 5, kFast, 4>(120),
     make_entry_single<14, 5, kExact, 4>(122),
 #ifdef AGX_DIAG
@@ -19,6 +23,8 @@ const rb_entry kEntries[] = {
     // A/B: forward by the ticket loop with one table entry per chunk (120 VGPRs, no scratch): still -4 % (n = 16384) / -3..-5 % (n = 32768) against one
     // workgroup per frame -- the hand-over barrier and the thinner twiddle prefetch cost more than the overlapped store tail wins
     make_entry_single_dloop<14, 5, kLazy | (kOptStreamCh1 << 1), 4, true, true>(145),
+    // A/B: R = 4 (16 coefficients per thread) streamed with one table entry per chunk: 60-64 VGPRs, no scratch -> 8 waves/SIMD
+    make_entry_single<14, 4, kLazy | (kOptStreamCh1 << 1), 8>(160),
 #endif
 };
 }  // namespace AGX_TU
