@@ -18,6 +18,7 @@ const rb_entry kEntries[] = {
     make_entry_single<12, 5, kLazy | ((kOptPrio | kOptPrioBarrier) << 1), 4>(148),
     // A/B: R = 4 (16 coefficients per thread) streamed with one table entry per chunk: 60-64 VGPRs, no scratch -> 8 waves/SIMD
     make_entry_single<12, 4, kLazy | (kOptStreamCh1 << 1), 8>(161),
+    make_entry_single<12, 4, kLazy | ((kOptStreamCh1 | kOptPrio) << 1), 8>(165),
 #endif
 };
 }  // namespace AGX_TU

@@ -750,7 +750,7 @@ REGISTRY = [
     (51, 16384, 62), (52, 16384, 61), (53, 16384, 60), (54, 32768, 60), (55, 32768, 61), (56, 32768, 62),
     # whole-frame R = 5 kernels (117 / 119 defaults, 120-123 fast / exact forms, 114-116 / 118 A/B)
     (117, 16384, 60), (119, 32768, 60), (120, 16384, 61), (121, 32768, 61), (122, 16384, 62), (123, 32768, 62),
-    (114, 32768, 60), (115, 16384, 60), (116, 32768, 60), (118, 16384, 60), (124, 16384, 60), (125, 32768, 60), (145, 16384, 60), (146, 32768, 60), (160, 16384, 60), (161, 4096, 60), (162, 8192, 60), (164, 16384, 60), (127, 4096, 60), (147, 4096, 60), (148, 4096, 60), (159, 4096, 60), (129, 1024, 60), (149, 1024, 60),
+    (114, 32768, 60), (115, 16384, 60), (116, 32768, 60), (118, 16384, 60), (124, 16384, 60), (125, 32768, 60), (145, 16384, 60), (146, 32768, 60), (160, 16384, 60), (161, 4096, 60), (165, 4096, 60), (162, 8192, 60), (164, 16384, 60), (127, 4096, 60), (147, 4096, 60), (148, 4096, 60), (159, 4096, 60), (129, 1024, 60), (149, 1024, 60),
     # streamed single-frame kernels of n = 1024 / 2048 / 8192 (lazy, fast, exact)
     (150, 1024, 60), (151, 1024, 61), (152, 1024, 62), (153, 2048, 60), (154, 2048, 61), (155, 2048, 62), (156, 8192, 60), (157, 8192, 61), (158, 8192, 62),
     # 32-bit arithmetic: tier 2 (every q < 2^30), tier 1 (every q < 2^31)
