@@ -23,7 +23,8 @@ const rb_entry kEntries[] = {
     // A/B: forward by the ticket loop with one table entry per chunk (120 VGPRs, no scratch): still -4 % (n = 16384) / -3..-5 % (n = 32768) against one
     // workgroup per frame -- the hand-over barrier and the thinner twiddle prefetch cost more than the overlapped store tail wins
     make_entry_single_dloop<14, 5, kLazy | (kOptStreamCh1 << 1), 4, true, true>(145),
-    // A/B: R = 4 (16 coefficients per thread) streamed with one table entry per chunk: 60-64 VGPRs, no scratch -> 8 waves/SIMD
+    // A/B: R = 4 (16 coefficients per thread) streamed with one table entry per chunk: 60-64 VGPRs, no scratch -> 8 waves/SIMD (its inverse by the
+    // ticket loop needs 60 B of scratch at 64 VGPRs and falls to 37.5 % against 40.4 % for id 117's: not registered)
     make_entry_single<14, 4, kLazy | (kOptStreamCh1 << 1), 8>(160),
 #endif
 };
