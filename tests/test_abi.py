@@ -48,6 +48,12 @@ def test_no_torch_or_oracle_in_product_library(agx):
     assert "amdhip64" in needed
 
 
+def test_release_caches_without_a_device(agx):
+    """agx_ntt_release_caches has nothing to free on a box without a GPU and must say so quietly (no HIP call may be required for it)"""
+    assert agx.lib().agx_ntt_release_caches() == 0
+    assert agx.lib().agx_ntt_release_caches() == 0
+
+
 def test_strerror(agx):
     L = agx.lib()
     assert L.agx_ntt_strerror(0) == b"success"
