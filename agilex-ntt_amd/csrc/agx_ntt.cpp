@@ -498,7 +498,7 @@ static int forward_common(const agx_ntt_plan* plan, const uint64_t* d_in, uint64
     fl.lazy_out = lazy_out;
     plan_view pv = view_of(plan);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (use_regblock(plan) && plan->rb_fwd.valid()) {      // the forward-only companion of the tuned default (n = 4096: +2.3 %)
+    if (use_regblock(plan) && plan->rb_fwd.valid() && batch * plan->num_primes >= plan->rb_fwd.min_frames) {      // the forward-only companion of the tuned default
         pv.rb = plan->rb_fwd;
         pv.tw_rb = plan->d_tw_rb_fwd;
     }

@@ -290,7 +290,9 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int 
 regblock_layout regblock_forward_companion(const regblock_layout& main, uint32_t n, int arith_level, int narrow_level) {
     const rb_entry* e = main.valid() ? rb_lookup(main.config_id) : nullptr;
     if (!e || e->fwd_companion <= 0) return regblock_layout{};
-    return regblock_choose(n, e->fwd_companion, arith_level, narrow_level);
+    regblock_layout rb = regblock_choose(n, e->fwd_companion, arith_level, narrow_level);
+    rb.min_frames = e->fwd_companion_min_frames;
+    return rb;
 }
 
 void regblock_build_table(const regblock_layout& rb, const uint64_t* tw, const uint64_t* pre, std::vector<ulonglong2>& out) {

@@ -23,6 +23,7 @@ struct regblock_layout {
     int r = 0;           // log2 coefficients per thread
     int config_id = -1;  // entry of the kernel registry in ntt_kernels.hip
     uint32_t pairs_per_prime = 0;  // table length per prime, in {w,w'} pairs
+    uint32_t min_frames = 0;       // forward companions: only launches of at least this many frames take this layout
     bool valid() const { return r > 0; }
 };
 

@@ -2020,8 +2020,9 @@ constexpr rb_entry make_entry_single(int id) {
 }
 
 // entry e with forward calls of its plans routed to the forward-only entry `id` (rb_entry::fwd_companion)
-constexpr rb_entry with_fwd_companion(rb_entry e, int id) {
+constexpr rb_entry with_fwd_companion(rb_entry e, int id, uint32_t min_frames = 0) {
     e.fwd_companion = id;
+    e.fwd_companion_min_frames = min_frames;
     return e;
 }
 

@@ -32,6 +32,8 @@ struct rb_entry {
     bool mul_parked = false;   // launch_mul keeps one frame in registers (the other parked in c's frame): legal at every log_local
     bool whole_only = false;   // the kernels assume the whole frame is resident (log_split = 0): never serves n = 2^(log_local + k)
     int fwd_companion = 0;     // registry id of a forward-only entry that serves forward calls of a plan whose main entry is this one (0: none)
+    uint32_t fwd_companion_min_frames = 0;   // ... for launches of at least this many frames (batch x primes): a shape with fewer threads per frame wins
+                                             // on throughput but loses on the latency of a launch that does not fill the chip
     int narrow = 0;            // 0: 64-bit arithmetic; 1: 32-bit arithmetic, every modulus < 2^31; 2: every modulus < 2^30 (rb32_kernels.hpp)
 };
 

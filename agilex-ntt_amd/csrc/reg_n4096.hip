@@ -8,7 +8,7 @@ namespace AGX_TU {
 // n = 4096 defaults: wave priority raised from launch until the frame's one all-wave barrier has been passed (+2 %);
 // 93 = 16q-lazy with the tail-free subtract schedule and quotient-estimate final reduction (q <= 2^60), 92 = fast (q <= 2^61), 91 = exact (q < 2^62)
 const rb_entry kEntries[] = {
-    with_fwd_companion(make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8>(93), 159),      // forward calls go to the streamed 128-thread kernel of reg_s4096.hip (+2.3 %)   // 90 + tail-free subtract schedule and quotient-estimate final reduction
+    with_fwd_companion(make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptEstReduce) << 1), 8>(93), 159, 4096),      // forward launches of >= 4,096 frames go to the streamed 128-thread kernel of reg_s4096.hip (+2.3 %); smaller ones stay here (512 threads per frame: 12.6 vs 18.7 us for BASELINE configs[1]'s batch-1 forward + inverse pair)   // 90 + tail-free subtract schedule and quotient-estimate final reduction
     make_entry2<12, 3, 1, 0 | ((kOptPad | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(91),
     make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase) << 1), 8>(92),
 #ifdef AGX_DIAG

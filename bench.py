@@ -172,7 +172,7 @@ def _timed(torch, fn, launches, warmup):
     return e0.elapsed_time(e1) / launches
 
 
-PROFILE_TAG = "r03e"      # the committed per-operation counter summaries the secondary lines point at
+PROFILE_TAG = "r03f"      # the committed per-operation counter summaries the secondary lines point at
 
 
 def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None, idle_w=None):
