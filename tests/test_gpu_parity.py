@@ -412,7 +412,7 @@ def test_large_frames_fast_and_exact_forms(agx, orc, dev, n, bits):
     plan.close()
 
 
-@pytest.mark.parametrize("n,batch", [(4096, 8), (16384, 300)])
+@pytest.mark.parametrize("n,batch", [(4096, 8), (4096, 4200), (16384, 300)])
 def test_calls_are_graph_capturable(agx, orc, dev, n, batch):
     """the device-pointer calls allocate nothing and never synchronise, so a stream capture can
     record them: forward + inverse captured once into a HIP graph, replayed on new data (n=16384 with more frames than
@@ -445,6 +445,29 @@ def test_calls_are_graph_capturable(agx, orc, dev, n, batch):
         assert np.array_equal(dev.to_host(mid), orc.forward(x, q, tw, pre, n))
         assert np.array_equal(dev.to_host(out), x)
     plan.close()
+
+
+def test_forward_companion_on_both_sides_of_its_threshold(agx, orc, dev):
+    """n = 4096, 60-bit moduli: forward launches of >= 4,096 frames run on the streamed 128-thread kernel (registry id 159, the forward companion
+    of the R = 3 default), smaller ones on the 512-thread kernel; one plan, launch sizes on both sides of the threshold (and exactly on it, split
+    over two primes), in place and out of place, every result against the oracle, inverse round trip through the main kernel"""
+    n = 4096
+    for primes, batch in ((1, 4095), (1, 4096), (2, 2047), (2, 2048), (3, 1400)):
+        plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
+        rng = np.random.default_rng(primes * 10000 + batch)
+        x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=4) for t in tabs])
+        want = np.concatenate([orc.forward_mt(x[p * batch * n:(p + 1) * batch * n].copy(), t[0], t[2], t[3], n, 8) for p, t in enumerate(tabs)])
+        d_x, d_y = dev.to_device(x), dev.empty(x.size)
+        plan.forward(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+        assert np.array_equal(dev.to_host(d_y), want), (primes, batch, "out of place")
+        plan.forward(d_x.data_ptr(), d_x.data_ptr(), batch, dev.stream)
+        assert np.array_equal(dev.to_host(d_x), want), (primes, batch, "in place")
+        plan.inverse(d_x.data_ptr(), d_x.data_ptr(), batch, dev.stream)
+        back = dev.to_host(d_x)
+        for p, t in enumerate(tabs):
+            sl = slice(p * batch * n, (p + 1) * batch * n)
+            assert np.array_equal(back[sl], x[sl] % np.uint64(t[0])), (primes, batch, "round trip")
+        plan.close()
 
 
 def test_empty_batch_and_errors(agx, dev):
