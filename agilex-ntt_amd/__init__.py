@@ -34,6 +34,7 @@ ABI = {
     "agx_ntt_device_count": (_int, [ctypes.POINTER(_int)]),
     "agx_ntt_forward_host": (_int, [_p64, _p64, _p64, _p64, _p64, _p64, _u32, _u32]),
     "agx_ntt_forward_host_stream": (_int, [_vp, _p64, _p64, _p64, _u64]),
+    "agx_ntt_inverse_host_stream": (_int, [_vp, _p64, _p64, _u64]),
     "agx_ntt_release_caches": (_int, []),
     "agx_ntt_plan_create": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64, _p64, _p64, _p64]),
     "agx_ntt_plan_create_auto": (_int, [ctypes.POINTER(_vp), _u32, _u32, _p64, _p64]),
@@ -53,6 +54,19 @@ ABI = {
     "agx_ntt_min_root": (_int, [_u64, _u32, _p64]),
     "agx_ntt_make_tables": (_int, [_u64, _u64, _u32, _p64, _p64]),
     "agx_ntt_make_inverse_tables": (_int, [_u64, _u64, _u32, _p64, _p64]),
+    # groups: the same calls over several GPUs (one shard, one host thread, one stream per listed device)
+    "agx_ntt_shard_range": (_int, [_u64, _u32, _u32, _p64, _p64]),
+    "agx_ntt_group_create": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_int), _u32, _u32, _u32, _p64, _p64, _p64, _p64, _p64]),
+    "agx_ntt_group_create_auto": (_int, [ctypes.POINTER(_vp), ctypes.POINTER(_int), _u32, _u32, _u32, _p64, _p64]),
+    "agx_ntt_group_destroy": (_int, [_vp]),
+    "agx_ntt_group_info": (_int, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "agx_ntt_group_shard": (_int, [_vp, _u32, ctypes.POINTER(_int), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "agx_ntt_group_forward_host": (_int, [_vp, _p64, _p64, _p64, _u64]),
+    "agx_ntt_group_inverse_host": (_int, [_vp, _p64, _p64, _u64]),
+    "agx_ntt_group_forward": (_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _p64]),
+    "agx_ntt_group_inverse": (_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _p64]),
+    "agx_ntt_group_polymul": (_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _p64]),
+    "agx_ntt_group_synchronize": (_int, [_vp]),
 }
 
 
@@ -275,9 +289,106 @@ class Plan:
         _check(lib().agx_ntt_forward_host_stream(self._h, _np_ptr(in1), _np_ptr(in2), _np_ptr(out), num_frames), "forward_host_stream")
         return out
 
+    def inverse_host_stream(self, in1, num_frames, out=None):
+        import numpy as np
+
+        if out is None:
+            out = np.zeros(num_frames * self.n, dtype=np.uint64)
+        _check(lib().agx_ntt_inverse_host_stream(self._h, _np_ptr(in1), _np_ptr(out), num_frames), "inverse_host_stream")
+        return out
+
     def close(self):
         if self._h:
             lib().agx_ntt_plan_destroy(self._h)
+            self._h = _vp(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_block(num_frames, num_shards, index):
+    """(first, count) of shard `index` when num_frames frames are dealt to num_shards shards (agx_ntt_shard_range: the reference's
+    minibatch sizes, src/kernel/ntt.cpp:526-536, as contiguous blocks); pure arithmetic, no device needed"""
+    first, count = _u64(0), _u64(0)
+    _check(lib().agx_ntt_shard_range(num_frames, num_shards, index, ctypes.byref(first), ctypes.byref(count)), "shard_range")
+    return first.value, count.value
+
+
+class DeviceGroup:
+    """One shard (plan + stream + staging + host thread) per entry of `devices` (agx_ntt_group_*): host frames are dealt in contiguous
+    blocks, device-pointer calls take one pointer per shard.  No collective anywhere."""
+
+    def __init__(self, devices, n, moduli, psi=None, tables=None):
+        import numpy as np
+
+        self.n = int(n)
+        self.devices = [int(d) for d in devices]
+        self.moduli = [int(q) for q in moduli]
+        mods = np.array(self.moduli, dtype=np.uint64)
+        devs = (_int * len(self.devices))(*self.devices)
+        self._h = _vp(None)
+        if tables is None:
+            psi_arr = None if psi is None else np.array([int(p) for p in psi], dtype=np.uint64)
+            _check(lib().agx_ntt_group_create_auto(ctypes.byref(self._h), devs, len(self.devices), self.n, len(self.moduli), _np_ptr(mods),
+                                                   None if psi_arr is None else _np_ptr(psi_arr)), "group_create_auto")
+        else:
+            tw, pre = (np.ascontiguousarray(t, dtype=np.uint64) for t in tables[:2])
+            itw = ipre = None
+            if len(tables) == 4:
+                itw, ipre = (np.ascontiguousarray(t, dtype=np.uint64) for t in tables[2:])
+            _check(lib().agx_ntt_group_create(ctypes.byref(self._h), devs, len(self.devices), self.n, len(self.moduli), _np_ptr(mods), _np_ptr(tw),
+                                              _np_ptr(pre), None if itw is None else _np_ptr(itw), None if ipre is None else _np_ptr(ipre)), "group_create")
+
+    @property
+    def num_shards(self):
+        return len(self.devices)
+
+    def shard(self, index):
+        """(device, plan handle, stream handle) of shard `index`; the handles belong to the group"""
+        dev, plan, stream = _int(0), _vp(None), _vp(None)
+        _check(lib().agx_ntt_group_shard(self._h, index, ctypes.byref(dev), ctypes.byref(plan), ctypes.byref(stream)), "group_shard")
+        return dev.value, plan.value, stream.value
+
+    def forward_host(self, in1, in2, num_frames, out=None):
+        import numpy as np
+
+        if out is None:
+            out = np.zeros(num_frames * self.n, dtype=np.uint64)
+        _check(lib().agx_ntt_group_forward_host(self._h, _np_ptr(in1), _np_ptr(in2), _np_ptr(out), num_frames), "group_forward_host")
+        return out
+
+    def inverse_host(self, in1, num_frames, out=None):
+        import numpy as np
+
+        if out is None:
+            out = np.zeros(num_frames * self.n, dtype=np.uint64)
+        _check(lib().agx_ntt_group_inverse_host(self._h, _np_ptr(in1), _np_ptr(out), num_frames), "group_inverse_host")
+        return out
+
+    def _ptrs(self, ptrs):
+        return None if ptrs is None else (_vp * self.num_shards)(*[int(p) if p else None for p in ptrs])
+
+    def _batches(self, batch):
+        return (_u64 * self.num_shards)(*[int(b) for b in batch])
+
+    def forward(self, d_in, d_out, batch):
+        _check(lib().agx_ntt_group_forward(self._h, self._ptrs(d_in), self._ptrs(d_out), self._batches(batch)), "group_forward")
+
+    def inverse(self, d_in, d_out, batch):
+        _check(lib().agx_ntt_group_inverse(self._h, self._ptrs(d_in), self._ptrs(d_out), self._batches(batch)), "group_inverse")
+
+    def polymul(self, d_a, d_b, d_c, batch, d_scratch=None):
+        _check(lib().agx_ntt_group_polymul(self._h, self._ptrs(d_a), self._ptrs(d_b), self._ptrs(d_c), self._ptrs(d_scratch), self._batches(batch)), "group_polymul")
+
+    def synchronize(self):
+        _check(lib().agx_ntt_group_synchronize(self._h), "group_synchronize")
+
+    def close(self):
+        if self._h:
+            lib().agx_ntt_group_destroy(self._h)
             self._h = _vp(None)
 
     def __del__(self):

@@ -17,6 +17,7 @@
 
 #include "host_math.hpp"
 #include "ntt_kernels.hpp"
+#include "plan_internal.hpp"
 #ifdef AGX_DIAG
 #include "../../tools/agx_ntt_diag.h"
 namespace agx { hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves); }
@@ -24,49 +25,16 @@ namespace agx { hipError_t regblock_set_trace(uint64_t* buf, uint64_t waves); }
 
 using namespace agx;
 
-constexpr uint32_t kTicketSlots = 64;    // distinct streams of one plan that may run ticket-drawing kernels; further streams get the stateless kernels
-
-struct agx_ntt_plan {
-    uint32_t n = 0, log_n = 0, num_primes = 0;
-    int device = -1;
-    int variant = AGX_VARIANT_AUTO;
-    bool has_inverse = false;
-    int arith_level = 0;     // 0 exact only; 1: every modulus <= 2^61 (8q-lazy legal); 2: <= 2^60 (16q-lazy legal)
-    int narrow_level = 0;    // 1: every modulus < 2^31, 2: < 2^30 -- the 32-bit kernels are legal (with arith_level >= 1: tables honour the contract)
-    std::vector<uint64_t> moduli, psi;  // psi = 0 when the tables came from the caller
-    prime_consts* d_consts = nullptr;
-    ulonglong2* d_tw = nullptr;
-    ulonglong2* d_itw = nullptr;
-    ulonglong2* d_tw_rb = nullptr;
-    ulonglong2* d_itw_rb = nullptr;
-    regblock_layout rb;
-    regblock_layout rb_fwd;            // forward-only layout (another kernel shape that is faster for the forward transform), or invalid
-    ulonglong2* d_tw_rb_fwd = nullptr;
-    // {next frame, retired workgroups} pairs for the kernels that hand out frames dynamically (the loop kernels of n >= 16384; diag
-    // ids 83/84), one pair per STREAM: launches on one stream run one after the other, and the last workgroup of a launch zeroes the
-    // pair, so a stream's launches can share one; launches on different streams get different pairs.  Only a launcher that needs a
-    // pair asks for one (plan_view::ticket).  A stream beyond the kTicketSlots-th gets none and its launches take the stateless
-    // fixed-stride kernels.  A slot is never recycled (a destroyed stream's handle may be reused by a new stream: that is still ONE
-    // stream at a time, so sharing its pair stays safe).
-    uint32_t* d_ticket = nullptr;
-    mutable std::mutex ticket_mu;
-    mutable std::vector<hipStream_t> ticket_streams;
-};
-
-namespace {
-
 thread_local int g_last_hip_error = 0;
 
+namespace agx {
 int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;
     return e == hipErrorOutOfMemory ? AGX_ERR_ALLOC : AGX_ERR_HIP;
 }
+}  // namespace agx
 
-#define AGX_HIP(expr)                                    \
-    do {                                                 \
-        hipError_t e_ = (expr);                          \
-        if (e_ != hipSuccess) return hip_fail(e_);       \
-    } while (0)
+namespace {
 
 // function attributes (large dynamic LDS) are per device and never change: set them once per device,
 // not on every plan creation
@@ -77,18 +45,6 @@ hipError_t kernels_init_once(int device) {
     if (device < 0 || device >= kMaxDevices) return kernels_init();
     std::call_once(once[device], [device] { result[device] = kernels_init(); });
     return result[device];
-}
-
-// nothing may propagate across the C boundary: std::vector / std::thread can throw inside the entry points below
-template <class F>
-int guarded(F&& f) {
-    try {
-        return f();
-    } catch (const std::bad_alloc&) {
-        return AGX_ERR_ALLOC;
-    } catch (...) {
-        return AGX_ERR_BAD_ARGUMENT;
-    }
 }
 
 int check_size(uint32_t n) {
@@ -105,6 +61,9 @@ int check_modulus(uint64_t q, uint32_t n) {
 uint32_t* plan_ticket_for(void* ctx, hipStream_t s) {
     const agx_ntt_plan* p = static_cast<const agx_ntt_plan*>(ctx);
     if (!p->d_ticket) return nullptr;
+    // hipStreamPerThread is ONE handle value that names a different stream in every host thread: two threads launching on "it" run
+    // concurrently and must not share a pair.  No pair is provably free for it: stateless fixed-stride kernels.
+    if (s == hipStreamPerThread) return nullptr;
     std::lock_guard<std::mutex> lock(p->ticket_mu);
     for (size_t i = 0; i < p->ticket_streams.size(); ++i)
         if (p->ticket_streams[i] == s) return p->d_ticket + 2 * i;
@@ -129,18 +88,6 @@ plan_view view_of(const agx_ntt_plan* p) {
     return v;
 }
 
-void free_plan(agx_ntt_plan* p) {
-    if (!p) return;
-    if (p->d_consts) (void)hipFree(p->d_consts);
-    if (p->d_ticket) (void)hipFree(p->d_ticket);
-    if (p->d_tw) (void)hipFree(p->d_tw);
-    if (p->d_itw) (void)hipFree(p->d_itw);
-    if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
-    if (p->d_itw_rb) (void)hipFree(p->d_itw_rb);
-    if (p->d_tw_rb_fwd) (void)hipFree(p->d_tw_rb_fwd);
-    delete p;
-}
-
 template <typename T>
 int upload(T** dst, const std::vector<T>& src) {
     AGX_HIP(hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(T)));
@@ -156,58 +103,63 @@ uint64_t inv_pow2_mod(uint32_t log_n, uint64_t q) {
     return r;
 }
 
-int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64_t* moduli, const uint64_t* psi,
-               const uint64_t* tw, const uint64_t* pre, const uint64_t* itw, const uint64_t* ipre) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AGX_ERR_NO_DEVICE;
-    agx_ntt_plan* p = new (std::nothrow) agx_ntt_plan;
-    if (!p) return AGX_ERR_ALLOC;
-    p->n = n;
-    p->log_n = (uint32_t)log2u(n);
-    p->num_primes = num_primes;
-    p->has_inverse = itw != nullptr;
-    p->ticket_streams.reserve(kTicketSlots);      // plan_ticket_for() runs inside unguarded launch calls: it must never allocate
-    p->moduli.assign(moduli, moduli + num_primes);
-    p->psi.assign(num_primes, 0);
-    if (psi) p->psi.assign(psi, psi + num_primes);
-    int rc = AGX_OK;
-    hipError_t he = hipGetDevice(&p->device);
-    if (he == hipSuccess) he = kernels_init_once(p->device);
-    if (he != hipSuccess) { free_plan(p); return hip_fail(he); }
+}  // namespace
 
-    std::vector<prime_consts> consts(num_primes);
-    std::vector<ulonglong2> tw_pairs((size_t)num_primes * n), itw_pairs;
-    if (itw) itw_pairs.resize((size_t)num_primes * n);
+namespace agx {
+
+void free_plan(agx_ntt_plan* p) {
+    if (!p) return;
+    if (p->d_consts) (void)hipFree(p->d_consts);
+    if (p->d_ticket) (void)hipFree(p->d_ticket);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_itw) (void)hipFree(p->d_itw);
+    if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
+    if (p->d_itw_rb) (void)hipFree(p->d_itw_rb);
+    if (p->d_tw_rb_fwd) (void)hipFree(p->d_tw_rb_fwd);
+    delete p;
+}
+
+void prepare_plan_image(plan_image& img, uint32_t n, uint32_t num_primes, const uint64_t* moduli, const uint64_t* psi,
+                        const uint64_t* tw, const uint64_t* pre, const uint64_t* itw, const uint64_t* ipre) {
+    img.n = n;
+    img.log_n = (uint32_t)log2u(n);
+    img.num_primes = num_primes;
+    img.has_inverse = itw != nullptr;
+    img.moduli.assign(moduli, moduli + num_primes);
+    img.psi.assign(num_primes, 0);
+    if (psi) img.psi.assign(psi, psi + num_primes);
+    img.consts.assign(num_primes, prime_consts{});
+    img.tw_pairs.resize((size_t)num_primes * n);
+    if (itw) img.itw_pairs.resize((size_t)num_primes * n);
     // The fast butterfly is only value-equivalent to the reference's when every modulus is <= 2^61
     // and the tables honour the contract precon[j] = floor(twiddle[j] * 2^64 / q), twiddle[j] < q.
     // Tables that do not (e.g. the placeholders of the reference's main.cpp:49-55) get the exact
     // kernels, which repeat the reference's operations mod 2^64 whatever they are fed.
-    p->arith_level = 2;
-    for (uint32_t k = 0; k < num_primes && p->arith_level > 0; ++k) {
+    img.arith_level = 2;
+    for (uint32_t k = 0; k < num_primes && img.arith_level > 0; ++k) {
         const uint64_t q = moduli[k];
-        if (q > (1ull << 60)) p->arith_level = std::min(p->arith_level, 1);
-        if (q > (1ull << 61)) p->arith_level = 0;
-        for (uint32_t j = 1; j < n && p->arith_level > 0; ++j) {
+        if (q > (1ull << 60)) img.arith_level = std::min(img.arith_level, 1);
+        if (q > (1ull << 61)) img.arith_level = 0;
+        for (uint32_t j = 1; j < n && img.arith_level > 0; ++j) {
             const uint64_t w = tw[(size_t)k * n + j];
-            if (w >= q || pre[(size_t)k * n + j] != shoup_quotient(w, q)) p->arith_level = 0;
+            if (w >= q || pre[(size_t)k * n + j] != shoup_quotient(w, q)) img.arith_level = 0;
             // the inverse kernels of a plan use the same arithmetic form: its tables must honour the contract too
-            if (itw && p->arith_level > 0) {
+            if (itw && img.arith_level > 0) {
                 const uint64_t iw = itw[(size_t)k * n + j];
-                if (iw >= q || ipre[(size_t)k * n + j] != shoup_quotient(iw, q)) p->arith_level = 0;
+                if (iw >= q || ipre[(size_t)k * n + j] != shoup_quotient(iw, q)) img.arith_level = 0;
             }
         }
     }
-    p->narrow_level = 2;
+    img.narrow_level = 2;
     for (uint32_t k = 0; k < num_primes; ++k) {
-        if (moduli[k] >= (1ull << 30)) p->narrow_level = std::min(p->narrow_level, 1);
-        if (moduli[k] >= (1ull << 31)) p->narrow_level = 0;
+        if (moduli[k] >= (1ull << 30)) img.narrow_level = std::min(img.narrow_level, 1);
+        if (moduli[k] >= (1ull << 31)) img.narrow_level = 0;
     }
-    p->rb = regblock_choose(n, -1, p->arith_level, p->narrow_level);
-    p->rb_fwd = regblock_forward_companion(p->rb, n, p->arith_level, p->narrow_level);
-    std::vector<ulonglong2> rb_pairs, irb_pairs, fwd_pairs;
+    img.rb = regblock_choose(n, -1, img.arith_level, img.narrow_level);
+    img.rb_fwd = regblock_forward_companion(img.rb, n, img.arith_level, img.narrow_level);
     for (uint32_t k = 0; k < num_primes; ++k) {
         const uint64_t q = moduli[k];
-        prime_consts& c = consts[k];
+        prime_consts& c = img.consts[k];
         std::memset(&c, 0, sizeof(c));
         c.q = q;
         const unsigned __int128 mu = ~(unsigned __int128)0 / q;  // = floor(2^128 / q) for odd q > 1
@@ -223,35 +175,98 @@ int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64
             std::memcpy(&bits, &f, sizeof(bits));
             c.est = bits;
         }
-        c.n_inv = inv_pow2_mod(p->log_n, q);
+        c.n_inv = inv_pow2_mod(img.log_n, q);
         c.n_inv_p = shoup_quotient(c.n_inv, q);
         const uint64_t* twk = tw + (size_t)k * n;
         const uint64_t* prek = pre + (size_t)k * n;
-        for (uint32_t j = 0; j < n; ++j) tw_pairs[(size_t)k * n + j] = make_ulonglong2(twk[j], prek[j]);
+        for (uint32_t j = 0; j < n; ++j) img.tw_pairs[(size_t)k * n + j] = make_ulonglong2(twk[j], prek[j]);
         if (itw) {
             const uint64_t* itwk = itw + (size_t)k * n;
             const uint64_t* iprek = ipre + (size_t)k * n;
-            for (uint32_t j = 0; j < n; ++j) itw_pairs[(size_t)k * n + j] = make_ulonglong2(itwk[j], iprek[j]);
+            for (uint32_t j = 0; j < n; ++j) img.itw_pairs[(size_t)k * n + j] = make_ulonglong2(itwk[j], iprek[j]);
             c.w1n = mul_mod(itwk[1] % q, c.n_inv, q);
             c.w1n_p = shoup_quotient(c.w1n, q);
-            if (p->rb.valid()) regblock_build_table(p->rb, itwk, iprek, irb_pairs);
+            if (img.rb.valid()) regblock_build_table(img.rb, itwk, iprek, img.irb_pairs);
         }
-        if (p->rb.valid()) regblock_build_table(p->rb, twk, prek, rb_pairs);
-        if (p->rb_fwd.valid()) regblock_build_table(p->rb_fwd, twk, prek, fwd_pairs);
+        if (img.rb.valid()) regblock_build_table(img.rb, twk, prek, img.rb_pairs);
+        if (img.rb_fwd.valid()) regblock_build_table(img.rb_fwd, twk, prek, img.fwd_pairs);
     }
-    if ((rc = upload(&p->d_consts, consts)) != AGX_OK) { free_plan(p); return rc; }
+}
+
+int instantiate_plan(agx_ntt_plan** out, const plan_image& img) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AGX_ERR_NO_DEVICE;
+    agx_ntt_plan* p = new (std::nothrow) agx_ntt_plan;
+    if (!p) return AGX_ERR_ALLOC;
+    p->n = img.n;
+    p->log_n = img.log_n;
+    p->num_primes = img.num_primes;
+    p->has_inverse = img.has_inverse;
+    p->arith_level = img.arith_level;
+    p->narrow_level = img.narrow_level;
+    p->rb = img.rb;
+    p->rb_fwd = img.rb_fwd;
+    p->ticket_streams.reserve(kTicketSlots);      // plan_ticket_for() runs inside unguarded launch calls: it must never allocate
+    p->moduli = img.moduli;
+    p->psi = img.psi;
+    int rc = AGX_OK;
+    hipError_t he = hipGetDevice(&p->device);
+    if (he == hipSuccess) he = kernels_init_once(p->device);
+    if (he != hipSuccess) { free_plan(p); return hip_fail(he); }
+    if ((rc = upload(&p->d_consts, img.consts)) != AGX_OK) { free_plan(p); return rc; }
     {
         hipError_t te = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 2 * kTicketSlots * sizeof(uint32_t));
         if (te == hipSuccess) te = hipMemset(p->d_ticket, 0, 2 * kTicketSlots * sizeof(uint32_t));
         if (te != hipSuccess) { free_plan(p); return hip_fail(te); }
     }
-    if ((rc = upload(&p->d_tw, tw_pairs)) != AGX_OK) { free_plan(p); return rc; }
-    if (itw && (rc = upload(&p->d_itw, itw_pairs)) != AGX_OK) { free_plan(p); return rc; }
-    if (p->rb.valid() && (rc = upload(&p->d_tw_rb, rb_pairs)) != AGX_OK) { free_plan(p); return rc; }
-    if (p->rb.valid() && itw && (rc = upload(&p->d_itw_rb, irb_pairs)) != AGX_OK) { free_plan(p); return rc; }
-    if (p->rb_fwd.valid() && (rc = upload(&p->d_tw_rb_fwd, fwd_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if ((rc = upload(&p->d_tw, img.tw_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (img.has_inverse && (rc = upload(&p->d_itw, img.itw_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (p->rb.valid() && (rc = upload(&p->d_tw_rb, img.rb_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (p->rb.valid() && img.has_inverse && (rc = upload(&p->d_itw_rb, img.irb_pairs)) != AGX_OK) { free_plan(p); return rc; }
+    if (p->rb_fwd.valid() && (rc = upload(&p->d_tw_rb_fwd, img.fwd_pairs)) != AGX_OK) { free_plan(p); return rc; }
     *out = p;
     return AGX_OK;
+}
+
+}  // namespace agx
+
+namespace {
+
+int build_plan(agx_ntt_plan** out, uint32_t n, uint32_t num_primes, const uint64_t* moduli, const uint64_t* psi,
+               const uint64_t* tw, const uint64_t* pre, const uint64_t* itw, const uint64_t* ipre) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return AGX_ERR_NO_DEVICE;
+    plan_image img;
+    prepare_plan_image(img, n, num_primes, moduli, psi, tw, pre, itw, ipre);
+    return instantiate_plan(out, img);
+}
+
+// Do two frame sets of the same shape -- frame (p, b) at base + p prime_stride + b poly_stride, n elements each -- overlap without being
+// the same set?  Identical bases are in place (legal: a workgroup reads its frame before it writes it); otherwise NO frame of one may
+// touch any frame of the other, because workgroups run in any order (include/agx_ntt.h: AGX_ERR_BAD_ARGUMENT "overlapping in/out").
+// Interleaved layouts whose frames do not touch (out = in + n with poly_stride = 2n) are legal and pass.
+bool partial_overlap(const void* a, const void* b, uint32_t n, uint32_t num_primes, uint64_t batch, int64_t prime_stride, int64_t poly_stride) {
+    if (a == b || batch == 0) return false;
+    const int64_t delta = (int64_t)((reinterpret_cast<intptr_t>(b) - reinterpret_cast<intptr_t>(a)) / (intptr_t)sizeof(uint64_t));     // elements (both 8-byte aligned)
+    const int64_t extent = (int64_t)(num_primes - 1) * prime_stride + (int64_t)(batch - 1) * poly_stride + (int64_t)n;
+    if (delta >= extent || -delta >= extent) return false;      // disjoint ranges
+    // frames i of A and j of B touch iff |delta + dp prime_stride + db poly_stride| < n for their index differences (dp, db)
+    const int64_t P = (int64_t)num_primes, B = (int64_t)batch;
+    for (int64_t dp = -(P - 1); dp <= P - 1; ++dp) {
+        const int64_t base = delta + dp * prime_stride;
+        if (poly_stride == 0 || B == 1) {
+            if (base > -(int64_t)n && base < (int64_t)n) return true;
+            continue;
+        }
+        // db closest to -base / poly_stride, within [-(B-1), B-1]: try the two neighbours of the quotient
+        int64_t d0 = -base / poly_stride;
+        for (int64_t db = d0 - 1; db <= d0 + 1; ++db) {
+            const int64_t dbc = std::max<int64_t>(-(B - 1), std::min<int64_t>(B - 1, db));
+            const int64_t v = base + dbc * poly_stride;
+            if (v > -(int64_t)n && v < (int64_t)n) return true;
+        }
+    }
+    return false;
 }
 
 int check_call(const agx_ntt_plan* plan, const void* a, const void* b, uint64_t batch, int64_t prime_stride, int64_t poly_stride) {
@@ -261,6 +276,8 @@ int check_call(const agx_ntt_plan* plan, const void* a, const void* b, uint64_t 
     if (prime_stride < 0 || poly_stride < 0) return AGX_ERR_BAD_ARGUMENT;
     if (batch > 1 && poly_stride < (int64_t)plan->n) return AGX_ERR_BAD_ARGUMENT;   // frames would overlap
     if ((batch << (plan->log_n > 14 ? plan->log_n - 14 : 0)) > 0x7fffffffull) return AGX_ERR_BAD_ARGUMENT;  // grid.x limit
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 7u) != 0) return AGX_ERR_BAD_ARGUMENT;      // uint64_t data
+    if (partial_overlap(a, b, plan->n, plan->num_primes, batch, prime_stride, poly_stride)) return AGX_ERR_BAD_ARGUMENT;
     return AGX_OK;
 }
 
@@ -270,41 +287,38 @@ bool use_regblock(const agx_ntt_plan* plan) {
 }
 
 // ---- staging resources of the host-pointer pipeline (agx_ntt_forward_host_stream) ------------------------------------
-constexpr size_t kStageChunkBytes = (size_t)32 << 20;
+}  // namespace
 
-struct staging_set {
-    static constexpr int kSlots = 3;
-    uint64_t *pin_in[kSlots] = {}, *pin_out[kSlots] = {}, *dev[kSlots] = {};
-    hipStream_t st[kSlots] = {};
-    hipEvent_t done[kSlots] = {};
-    size_t bytes = 0;
-    hipError_t ensure(size_t want) {
-        if (bytes >= want) return hipSuccess;
-        destroy();
-        hipError_t e = hipSuccess;
-        for (int k = 0; k < kSlots && e == hipSuccess; ++k) {
-            e = hipHostMalloc(reinterpret_cast<void**>(&pin_in[k]), want, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pin_out[k]), want, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dev[k]), want);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
-        }
-        if (e == hipSuccess) bytes = want;
-        else destroy();
-        return e;
+namespace agx {
+hipError_t staging_set::ensure(size_t want) {
+    if (bytes >= want) return hipSuccess;
+    destroy();
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < kSlots && e == hipSuccess; ++k) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&pin_in[k]), want, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pin_out[k]), want, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dev[k]), want);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
     }
-    void destroy() {
-        for (int k = 0; k < kSlots; ++k) {
-            if (st[k]) { (void)hipStreamSynchronize(st[k]); (void)hipStreamDestroy(st[k]); }
-            if (done[k]) (void)hipEventDestroy(done[k]);
-            if (dev[k]) (void)hipFree(dev[k]);
-            if (pin_in[k]) (void)hipHostFree(pin_in[k]);
-            if (pin_out[k]) (void)hipHostFree(pin_out[k]);
-            st[k] = nullptr; done[k] = nullptr; dev[k] = nullptr; pin_in[k] = nullptr; pin_out[k] = nullptr;
-        }
-        bytes = 0;
+    if (e == hipSuccess) bytes = want;
+    else destroy();
+    return e;
+}
+void staging_set::destroy() {
+    for (int k = 0; k < kSlots; ++k) {
+        if (st[k]) { (void)hipStreamSynchronize(st[k]); (void)hipStreamDestroy(st[k]); }
+        if (done[k]) (void)hipEventDestroy(done[k]);
+        if (dev[k]) (void)hipFree(dev[k]);
+        if (pin_in[k]) (void)hipHostFree(pin_in[k]);
+        if (pin_out[k]) (void)hipHostFree(pin_out[k]);
+        st[k] = nullptr; done[k] = nullptr; dev[k] = nullptr; pin_in[k] = nullptr; pin_out[k] = nullptr;
     }
-};
+    bytes = 0;
+}
+}  // namespace agx
+
+namespace {
 
 // one cached set per device, handed to one call at a time; a second concurrent call gets nullptr and builds its own
 constexpr int kPoolDevices = 64;
@@ -544,6 +558,7 @@ int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint6
     if (!plan || !d_a || !d_b || !d_c) return AGX_ERR_NULL_POINTER;
     int rc = check_call(plan, d_a, d_c, batch, (int64_t)(batch * plan->n), (int64_t)plan->n);
     if (rc) return rc;
+    if ((rc = check_call(plan, d_b, d_c, batch, (int64_t)(batch * plan->n), (int64_t)plan->n))) return rc;
     if (batch == 0) return AGX_OK;
     AGX_HIP(launch_pointwise(view_of(plan), d_a, d_b, d_c, batch, static_cast<hipStream_t>(stream)));
     return AGX_OK;
@@ -554,6 +569,7 @@ int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_
     if (!plan || !d_a || !d_b || !d_c) return AGX_ERR_NULL_POINTER;
     int rc = check_call(plan, d_a, d_c, batch, (int64_t)(batch * plan->n), (int64_t)plan->n);
     if (rc) return rc;
+    if ((rc = check_call(plan, d_b, d_c, batch, (int64_t)(batch * plan->n), (int64_t)plan->n))) return rc;      // c may BE a or b, never straddle them
     if (!plan->has_inverse) return AGX_ERR_NO_INVERSE;
     if (batch == 0) return AGX_OK;
     if (use_regblock(plan) && regblock_has_polymul(plan->rb) && plan->d_itw_rb) {
@@ -564,7 +580,9 @@ int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_
         return AGX_OK;
     }
     if (!d_scratch) return AGX_ERR_NULL_POINTER;
-    if (d_scratch == d_a || d_scratch == d_b || d_scratch == d_c) return AGX_ERR_BAD_ARGUMENT;
+    for (const uint64_t* other : {d_a, d_b, (const uint64_t*)d_c})      // the scratch frames must not touch a, b or c anywhere
+        if (d_scratch == other || partial_overlap(other, d_scratch, plan->n, plan->num_primes, batch, (int64_t)(batch * plan->n), (int64_t)plan->n))
+            return AGX_ERR_BAD_ARGUMENT;
     // scratch <- NTT(a); c <- NTT(b) (a is dead by now, so c may alias it); c <- INTT(c o scratch).
     // With the register-blocked inverse the product is taken while it loads (no pointwise pass) and
     // the forward results may stay lazily reduced.
@@ -596,27 +614,34 @@ int agx_ntt_fill_synthetic(const agx_ntt_plan* plan, uint64_t* d_out, uint64_t b
 // (src/kernel/ntt.cpp:508-640).  Three slots of pinned staging + device memory rotate over three
 // streams: while slot k computes, slot k+1 uploads and the host thread assembles slot k+2
 // (lower half of each frame from `in`, upper half from `in2`, src/kernel/ntt.cpp:584-590).
-static int forward_host_stream_impl(const agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2, uint64_t* out, uint64_t num_frames);
-
 int agx_ntt_forward_host_stream(const agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2, uint64_t* out,
                                 uint64_t num_frames) {
-    try {      // std::thread / std::vector inside may throw: nothing crosses the C boundary
-        return forward_host_stream_impl(plan, in, in2, out, num_frames);
-    } catch (const std::bad_alloc&) {
-        return AGX_ERR_ALLOC;
-    } catch (...) {
-        return AGX_ERR_BAD_ARGUMENT;
-    }
+    return guarded([&] { return host_stream_pipeline(plan, in, in2, out, num_frames, false, nullptr); });      // std::thread / std::vector inside may throw
 }
 
-static int forward_host_stream_impl(const agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2, uint64_t* out, uint64_t num_frames) {
+// the inverse transform through the same pipeline (bit-reversed order in, natural order out; no operand pairing: the reference has no
+// inverse path)
+int agx_ntt_inverse_host_stream(const agx_ntt_plan* plan, const uint64_t* in, uint64_t* out, uint64_t num_frames) {
+    return guarded([&] { return host_stream_pipeline(plan, in, in, out, num_frames, true, nullptr); });
+}
+
+}  // extern "C"
+
+namespace agx {
+
+int host_stream_pipeline(const agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2, uint64_t* out, uint64_t num_frames,
+                         bool inverse, staging_set* own) {
     if (!plan || !in || !in2 || !out) return AGX_ERR_NULL_POINTER;
     if (plan->num_primes != 1) return AGX_ERR_BAD_ARGUMENT;   // one modulus per stream, as the reference (ntt.cpp:143-144)
+    if (inverse && !plan->has_inverse) return AGX_ERR_NO_INVERSE;
     {
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess || dev != plan->device) return AGX_ERR_BAD_ARGUMENT;   // staging memory is allocated on the current device
     }
     if (num_frames == 0) return AGX_OK;
+    auto transform = [&](uint64_t* d, uint64_t frames, hipStream_t s) {
+        return inverse ? agx_ntt_inverse(plan, d, d, frames, s) : agx_ntt_forward(plan, d, d, frames, s);
+    };
     const size_t n = plan->n, row = n * sizeof(uint64_t), half = row / 2;
     if (num_frames * row <= ((size_t)4 << 20)) {
         // small inputs: staging buffers and streams would cost more than they hide
@@ -626,7 +651,7 @@ static int forward_host_stream_impl(const agx_ntt_plan* plan, const uint64_t* in
         if (se == hipSuccess) se = hipMemcpy2D(d, row, in, row, half, num_frames, hipMemcpyHostToDevice);
         if (se == hipSuccess) se = hipMemcpy2D(reinterpret_cast<char*>(d) + half, row, reinterpret_cast<const char*>(in2) + half, row, half, num_frames, hipMemcpyHostToDevice);
         if (se == hipSuccess) {
-            src = agx_ntt_forward(plan, d, d, num_frames, nullptr);
+            src = transform(d, num_frames, nullptr);
             if (src == AGX_OK) se = hipMemcpy(out, d, row * num_frames, hipMemcpyDeviceToHost);
         }
         if (d) (void)hipFree(d);
@@ -637,12 +662,31 @@ static int forward_host_stream_impl(const agx_ntt_plan* plan, const uint64_t* in
     // byte is also copied once into and once out of pinned memory by the CPU; at ~12 GiB/s per core that staging, not
     // PCIe, is the bottleneck of a single-threaded pipeline (tools/host_stream_bench.py).  Hence: the staging copies of a
     // chunk are split over a few worker threads, the drain of chunk c-3 runs beside the staging of chunk c, and the
-    // pinned / device slots and streams are kept in a per-device pool between calls (allocating 192 MiB of pinned memory
-    // costs more than moving 1 GiB through it).
-    staging_set* set = acquire_staging(plan->device);
-    const bool pooled = set != nullptr;
-    staging_set local;
-    if (!set) set = &local;
+    // pinned / device slots and streams are kept between calls (allocating 192 MiB of pinned memory costs more than moving
+    // 1 GiB through it): in the caller's own set (a group's shard), else in a per-device pool.
+    // Whatever leaves this function -- a status, an exception from std::thread -- `lease` first waits for the slot streams and
+    // then gives the pooled set back / frees the temporary one (a throw used to leave the pool's lock held for good).
+    struct lease_t {
+        staging_set* set = nullptr;
+        staging_set local;
+        int pooled_device = -1;
+        ~lease_t() {
+            if (set)
+                for (int k = 0; k < staging_set::kSlots; ++k)
+                    if (set->st[k]) (void)hipStreamSynchronize(set->st[k]);
+            if (pooled_device >= 0) release_staging(pooled_device);
+            local.destroy();
+        }
+    } lease;
+    if (own) {
+        lease.set = own;
+    } else if (staging_set* pooled = acquire_staging(plan->device)) {
+        lease.set = pooled;
+        lease.pooled_device = plan->device;
+    } else {
+        lease.set = &lease.local;
+    }
+    staging_set* set = lease.set;
     hipError_t e = set->ensure(kStageChunkBytes);
     int rc = AGX_OK;
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(num_frames, kStageChunkBytes / row));
@@ -660,13 +704,13 @@ static int forward_host_stream_impl(const agx_ntt_plan* plan, const uint64_t* in
     };
     for (uint64_t c = 0; c < nchunks && e == hipSuccess && rc == AGX_OK; ++c) {
         const int k = (int)(c % slots);
-        std::thread drainer;
+        joining_thread drainer;      // joined on every path out of this iteration
         if (c >= (uint64_t)slots) {
             // slot k still belongs to chunk c-slots: done[k] (recorded behind its download) says its upload source
             // pin_in[k] is free again and its results sit in pin_out[k]
             e = hipEventSynchronize(set->done[k]);
             if (e != hipSuccess) break;
-            drainer = std::thread([&, c] { copy_out(c - slots); });     // beside the staging of chunk c
+            drainer = joining_thread([&, c] { copy_out(c - slots); });     // beside the staging of chunk c
         }
         const uint64_t f = frames_of(c);
         const uint64_t* a = in + c * chunk * n;
@@ -683,19 +727,19 @@ static int forward_host_stream_impl(const agx_ntt_plan* plan, const uint64_t* in
             });
         }
         e = hipMemcpyAsync(set->dev[k], set->pin_in[k], f * row, hipMemcpyHostToDevice, set->st[k]);
-        if (e == hipSuccess) rc = agx_ntt_forward(plan, set->dev[k], set->dev[k], f, set->st[k]);
-        if (drainer.joinable()) drainer.join();      // pin_out[k] must be empty before this chunk's download may land in it
+        if (e == hipSuccess) rc = transform(set->dev[k], f, set->st[k]);
+        drainer.join();      // pin_out[k] must be empty before this chunk's download may land in it
         if (e == hipSuccess && rc == AGX_OK) e = hipMemcpyAsync(set->pin_out[k], set->dev[k], f * row, hipMemcpyDeviceToHost, set->st[k]);
         if (e == hipSuccess && rc == AGX_OK) e = hipEventRecord(set->done[k], set->st[k]);
     }
     for (uint64_t c = nchunks > (uint64_t)slots ? nchunks - slots : 0; c < nchunks && e == hipSuccess && rc == AGX_OK; ++c) e = drain(c);
-    for (int k = 0; k < staging_set::kSlots; ++k)
-        if (set->st[k]) (void)hipStreamSynchronize(set->st[k]);
-    if (pooled) release_staging(plan->device);
-    else local.destroy();
     if (rc != AGX_OK) return rc;
     return e == hipSuccess ? AGX_OK : hip_fail(e);
 }
+
+}  // namespace agx
+
+extern "C" {
 
 // One-shot calls usually repeat with the same (n, modulus, tables): building a plan verifies every table
 // entry (a 128-bit divide each) and uploads four tables, which costs tens of milliseconds, so the last

@@ -218,7 +218,7 @@ namespace {
 template <class F>
 void for_each_entry(F&& f) {
     const rb_span groups[] = {rb_entries_n4096(), rb_entries_s1024(), rb_entries_s2048(), rb_entries_s4096(), rb_entries_s8192(), rb_entries_s16384(), rb_entries_s32768(),
-                              rb_entries_q32a(), rb_entries_q32b(),
+                              rb_entries_q32a(), rb_entries_q32b(), rb_entries_wp(), rb_entries_wp32(),
 #ifdef AGX_DIAG
                               rb_entries_n1024(), rb_entries_n2048(), rb_entries_n8192(), rb_entries_n4096_ab(), rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_gen1(), rb_entries_diag(),
 #endif
@@ -251,7 +251,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int 
     regblock_layout rb;
     int log_n = 0;
     while ((1u << log_n) < n) ++log_n;
-    if (log_n < 10) return rb;  // small sizes stay on the radix-2 kernel
+    if (log_n < 5) return rb;  // n < 32 stays on the radix-2 kernel
     // an entry serves n if its resident size plus its (fixed or default) number of split stages is log_n
     auto split_for = [&](const rb_entry& e) -> int {
         if (e.fused_split > 0) return e.log_local + e.fused_split == log_n ? e.fused_split : -1;
@@ -268,7 +268,9 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int 
         if (e && (split_for(*e) < 0 || !legal(*e))) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
-        static const int kDefaults[] = {130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141,      // narrow moduli: 32-bit arithmetic (tier 2, then tier 1)
+        static const int kDefaults[] = {230, 231, 232, 233, 234, 240, 241, 242, 243, 244,                 // n = 32 ... 512, narrow moduli: wave-packed 32-bit kernels (tier 2, then tier 1)
+                                        200, 201, 202, 203, 204, 205, 206, 207, 208, 209, 210, 211, 212, 213, 214,      // n = 32 ... 512: wave-packed kernels (16q-lazy, fast, exact per size)
+                                        130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141,      // narrow moduli: 32-bit arithmetic (tier 2, then tier 1)
                                         93, 92, 91,                                                      // n = 4096: R = 3, 8 waves/SIMD (16q-lazy, fast, exact)
                                         150, 151, 152, 153, 154, 155, 156, 157, 158,                     // n = 1024 / 2048 / 8192: streamed single-frame kernels
                                         119, 117, 121, 120, 123, 122};                                  // n = 32768 / 16384

@@ -101,7 +101,6 @@ template <int L, int R, int TIER>
 struct rb32_frame {
     using G = rb2_geom<L, R>;
     static constexpr int C = G::C, T = G::T, NP = G::NP;
-    static_assert(T >= 64, "one frame spans whole waves");
     static constexpr uint32_t slab_words = (1u << L) + (1u << (L - 5));
     // image word of coefficient e: one pad word per 32 (additive over disjoint bit fields: thread base + compile-time constant); of the
     // shifts 3..7 this one leaves the fewest bank conflicts for 32-bit accesses (32 banks per group of 32 lanes) at every (L, R) used here
@@ -134,7 +133,7 @@ struct rb32_frame {
     template <int p>
     __device__ __forceinline__ tw32 entry(const tw32* tbl, int j) const {
         constexpr int rlo = G::rlo(p), H = G::H(p);
-        if constexpr (rlo >= 6) {
+        if constexpr (G::uniform_pass(p)) {
             const uint32_t hcol = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> rlo));
             return load_uniform32(tbl + G::table_off(p) + (size_t)hcol * C + j);
         } else {
@@ -262,6 +261,7 @@ struct rb32_frame {
 #define AGX_RB32_PROLOGUE                                                                         \
     using F = rb32_frame<L, R, TIER>;                                                             \
     constexpr int C = F::C, T = F::T;                                                             \
+    static_assert(T >= 64, "one frame spans whole waves");                                        \
     F f;                                                                                          \
     f.tid = threadIdx.x & (T - 1);                                                                \
     const uint32_t slot = threadIdx.x / T;                                                        \

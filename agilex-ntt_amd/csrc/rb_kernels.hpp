@@ -191,6 +191,10 @@ struct rb2_geom : rb_geom<L, R> {
                 if ((owner(p + 1, elem(p, tid, r)) >> 6) != (tid >> 6)) return false;
         return true;
     }
+    // is pass p's twiddle column the same for every lane of a wave?  Either the column index (tid >> rlo) only changes from wave to
+    // wave (rlo >= 6), or the pass has a single column (H = 1: pass 0 of a whole frame; with fewer than 64 threads per frame -- the
+    // wave-packed kernels of wp_kernels.hpp -- that is the only way).  Such passes read their entries with scalar loads into SGPRs.
+    static constexpr bool uniform_pass(int p) { return G::rlo(p) >= 6 || G::H(p) == 1; }
     // after the last pass, does every wave hold one contiguous block of 64*C coefficients?
     static constexpr bool last_pass_wave_contiguous() { return G::rlo(G::NP - 1) == 0 && G::T >= 64; }
 };
@@ -409,7 +413,7 @@ struct rb2_frame {
     __device__ __forceinline__ void fetch(tw_src<p>& t, const twpair* tbl) const {
         constexpr int rlo = G::rlo(p), H = G::H(p);
         const uint32_t high = tid >> rlo;
-        if constexpr (rlo >= 6) {
+        if constexpr (G::uniform_pass(p)) {
             const uint32_t hcol = (uint32_t)__builtin_amdgcn_readfirstlane((int)high);
             const twpair* ucol = tbl + G::table_off(p) * (1u << split_log) + ((size_t)blk * H + hcol) * C;
             if constexpr (STREAM_TW) {
@@ -440,7 +444,7 @@ struct rb2_frame {
     }
     template <int p>
     __device__ __forceinline__ twpair twiddle(const tw_src<p>& t, int j) const {
-        if constexpr (G::rlo(p) >= 6) return t.tw[j];
+        if constexpr (G::uniform_pass(p)) return t.tw[j];
         else return lane_entry<p>(t.col, j);
     }
 
@@ -507,7 +511,7 @@ struct rb2_frame {
         constexpr int ns = G::hi(p) - G::rlo(p) + 1, S = st_stage(ns, q, INV), cc = st_chunk(ns, q, INV), kk = st_kk(ns, S, INV);
         static_for<0, st_count(ns, S, INV)>([&](auto I) {
             constexpr int j = (1 << kk) + cc * CH + (int)I;
-            if constexpr (G::rlo(p) >= 6) c.e[I] = load_uniform(t.col + j);
+            if constexpr (G::uniform_pass(p)) c.e[I] = load_uniform(t.col + j);
             else c.e[I] = lane_entry<p>(t.col, j);
         });
     }
@@ -1558,7 +1562,9 @@ polymul_rb2(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint
 // coefficients), multiplied, and the inverse starts from there.  This is what lets n = 16384 (16 coefficients per
 // thread: two frames do not fit 128 VGPRs) run the product in one launch, and what frees the smaller sizes from the
 // second frame's registers.  The host passes as `first` the operand c aliases, if any: a workgroup reads all of
-// `first` before it writes c, and `second` is then a different buffer.
+// `first` before it writes c, and `second` is then a different buffer.  Squaring (a == b, with or without c aliasing
+// them) never comes here: `second` would be the parked words themselves when c aliases too, so the
+// launcher sends it to polysquare_rb2 below (a branch on first == second inside this kernel cost 240-320 B of scratch).
 template <int L, int R, int ARITH, int MINW>
 __global__ void __launch_bounds__((1 << (L - R)), MINW)
 polymul_rb2_park(const uint64_t* __restrict__ first, const uint64_t* __restrict__ second, uint64_t* __restrict__ c,
@@ -1634,6 +1640,42 @@ polymul_rb2_park(const uint64_t* __restrict__ first, const uint64_t* __restrict_
         for (int r = 0; r < C; ++r) x[r] = mul_mod_barrett(z[r], x[r], bk);
     }
     __syncthreads();   // nobody overwrites c's frame (below) before everybody has fetched its parked part
+    f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            if constexpr (NTS) __builtin_nontemporal_store(x[r], &c[base + f.tid + (uint32_t)r * T]);
+            else c[base + f.tid + (uint32_t)r * T] = x[r];
+        }
+    }
+}
+
+// c = a * a in Z_q[X]/(X^n + 1): one forward transform, the product of every coefficient with itself where it sits in
+// registers, the inverse.  16n bytes of traffic; a workgroup reads its whole frame before it writes any of it, so c may
+// alias a.  Serves agx_ntt_polymul calls with a == b on the plans whose fused product is polymul_rb2_park.
+template <int L, int R, int ARITH, int MINW>
+__global__ void __launch_bounds__((1 << (L - R)), MINW)
+polysquare_rb2(const uint64_t* __restrict__ a, uint64_t* __restrict__ c,
+               const prime_consts* __restrict__ consts, const twpair* __restrict__ tw_rb, const twpair* __restrict__ itw_rb,
+               uint32_t pairs_per_prime, uint64_t frames_x, int64_t prime_stride, int64_t poly_stride) {
+    constexpr uint32_t split_log = 0;
+    constexpr int PPB = 1;
+    AGX_RB2_PROLOGUE;
+    const prime_consts pc = consts[prime];
+    const barrett128 bk{pc.q, pc.mu_hi, pc.mu_lo};
+    f.lazy_out = F::LAZY16;     // the Barrett product takes operands in [0,4q) when q <= 2^60
+    constexpr bool NTL = ((ARITH >> 1) & kOptNtLoad) != 0, NTS = ((ARITH >> 1) & kOptNtStore) != 0;
+    uint64_t x[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) x[r] = NTL ? __builtin_nontemporal_load(&a[base + f.tid + (uint32_t)r * T]) : a[base + f.tid + (uint32_t)r * T];
+    f.forward(x, tw_rb + (size_t)prime * pairs_per_prime);
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+        asm volatile("" : "+v"(x[r]));
+        x[r] = mul_mod_barrett(x[r], x[r], bk);
+        asm volatile("" : "+v"(x[r]));
+    }
+    __syncthreads();   // the image is reused: every wave is done reading the forward transform's exchanges
     f.inverse(x, itw_rb + (size_t)prime * pairs_per_prime, pc);
     if (live) {
 #pragma unroll
@@ -1734,6 +1776,11 @@ hipError_t launch_mul_park_t(const plan_view& pv, const uint64_t* a, const uint6
     using G = rb_geom<L, R>;
     dim3 grid((unsigned)fl.batch, pv.num_primes);
     const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>();
+    if (a == b) {      // squaring: NTT(a) times itself in registers (the parked form would read its own parked words back when c aliases too)
+        hipLaunchKernelGGL((polysquare_rb2<L, R, ARITH, MINW>), grid, dim3(G::T), lds, s, a, c, pv.consts,
+                           pv.tw_rb, pv.itw_rb, pv.rb.pairs_per_prime, fl.batch, fl.prime_stride, fl.poly_stride);
+        return hipGetLastError();
+    }
     // the operand c aliases (if any) must be the one that is read completely before c's frame is written
     const uint64_t* first = (c == b) ? b : a;
     const uint64_t* second = (c == b) ? a : b;
@@ -1744,8 +1791,11 @@ hipError_t launch_mul_park_t(const plan_view& pv, const uint64_t* a, const uint6
 
 template <int L, int R, int ARITH, int MINW>
 hipError_t init_mul_park_t() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&polymul_rb2_park<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)rb2_lds_bytes<L, R, 1, ARITH>());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polymul_rb2_park<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)rb2_lds_bytes<L, R, 1, ARITH>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polysquare_rb2<L, R, ARITH, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)rb2_lds_bytes<L, R, 1, ARITH>());
+    return e;
 }
 
 template <int L, int R, int PPB, int ARITH, int MINW>

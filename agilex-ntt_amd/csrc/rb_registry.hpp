@@ -53,6 +53,8 @@ rb_span rb_entries_s16384();
 rb_span rb_entries_s32768();
 rb_span rb_entries_q32a();       // 32-bit arithmetic, tier 2 (every modulus < 2^30) / tier 1 (< 2^31)
 rb_span rb_entries_q32b();
+rb_span rb_entries_wp();         // wave-packed kernels of n = 32 ... 512 (wp_kernels.hpp): 64-bit arithmetic / 32-bit arithmetic
+rb_span rb_entries_wp32();
 #ifdef AGX_DIAG
 // groups that only exist in lib/libagxntt_diag.so: earlier generations and measured-and-rejected shapes, kept selectable for A/B runs
 rb_span rb_entries_gen1();

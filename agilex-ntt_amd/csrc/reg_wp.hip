@@ -1,0 +1,29 @@
+// reg_wp.hip -- the wave-packed kernels of the small sizes, n = 32 ... 512, 64-bit arithmetic (wp_kernels.hpp); a group of the kernel
+// registry (rb_registry.hpp): ids are stable handles for tests and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices.
+#define AGX_TU tu_wp
+#include "rb_kernels.hpp"
+#include "wp_kernels.hpp"
+
+namespace agx {
+namespace AGX_TU {
+// streamed twiddles + pinned butterflies as in the single-frame kernels of the large sizes (rb_stream_opts.hpp), full 64-bit image
+constexpr int kWpLazy = 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptStreamTw | kOptPinBf) << 1);   // q <= 2^60
+constexpr int kWpFast = 1 | ((kOptPad | kOptSelect | kOptNtLoad | kOptNtStore | kOptStreamTw | kOptPinBf) << 1);                                            // q <= 2^61
+constexpr int kWpExact = 0 | ((kOptPad | kOptNtLoad | kOptNtStore | kOptStreamTw | kOptPinBf) << 1);                                                        // q < 2^62, reference op sequence
+const rb_entry kEntries[] = {
+    // n = 32: 8 coefficients per lane, 4 lanes per frame, 16 frames per wave
+    make_entry_wp<5, 3, 4, kWpLazy, 8>(200), make_entry_wp<5, 3, 4, kWpFast, 8>(201), make_entry_wp<5, 3, 4, kWpExact, 8>(202),
+    // n = 64: 8 x 8
+    make_entry_wp<6, 3, 4, kWpLazy, 8>(203), make_entry_wp<6, 3, 4, kWpFast, 8>(204), make_entry_wp<6, 3, 4, kWpExact, 8>(205),
+    // n = 128: 16 coefficients per lane, 8 lanes per frame
+    make_entry_wp<7, 4, 4, kWpLazy, 5>(206), make_entry_wp<7, 4, 4, kWpFast, 5>(207), make_entry_wp<7, 4, 4, kWpExact, 5>(208),
+    // n = 256: 16 x 16
+    make_entry_wp<8, 4, 4, kWpLazy, 5>(209), make_entry_wp<8, 4, 4, kWpFast, 5>(210), make_entry_wp<8, 4, 4, kWpExact, 5>(211),
+    // n = 512: 16 x 32
+    make_entry_wp<9, 4, 4, kWpLazy, 5>(212), make_entry_wp<9, 4, 4, kWpFast, 5>(213), make_entry_wp<9, 4, 4, kWpExact, 5>(214),
+};
+}  // namespace AGX_TU
+
+rb_span rb_entries_wp() { return rb_span{AGX_TU::kEntries, sizeof(AGX_TU::kEntries) / sizeof(AGX_TU::kEntries[0])}; }
+
+}  // namespace agx

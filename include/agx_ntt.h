@@ -85,6 +85,9 @@ AGX_API int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const 
 struct agx_ntt_plan;
 AGX_API int agx_ntt_forward_host_stream(const struct agx_ntt_plan* plan, const uint64_t* in, const uint64_t* in2,
                                 uint64_t* out, uint64_t num_frames);
+/* the inverse transform through the same pipeline (bit-reversed order in, natural order out, one modulus; the reference ships no */
+/* inverse path -- SURVEY F2 -- so there is no operand pairing to mirror)                                                         */
+AGX_API int agx_ntt_inverse_host_stream(const struct agx_ntt_plan* plan, const uint64_t* in, uint64_t* out, uint64_t num_frames);
 
 /* Releases what the library keeps between calls: the one-shot plan of every device (agx_ntt_forward_host keeps the plan of its */
 /* last call per device) and the per-device pool of pinned / device staging buffers of the streaming path (192 MiB pinned +     */
@@ -97,7 +100,9 @@ AGX_API int agx_ntt_release_caches(void);
 /* A plan is immutable after creation and may be shared between host threads   */
 /* and streams (kernels that hand out frames through a counter keep one counter */
 /* pair per stream, for up to 64 distinct streams per plan; launches on further */
-/* streams take a stateless kernel form: slower by a few per cent, never wrong); */
+/* streams -- and on hipStreamPerThread, one handle that names a different      */
+/* stream in every host thread -- take a stateless kernel form: slower by a few */
+/* per cent, never wrong);                                                       */
 /* it belongs to the HIP device that was current when it was created: calls    */
 /* that take it return AGX_ERR_BAD_ARGUMENT while another device is current.   */
 /* ------------------------------------------------------------------------- */
@@ -114,7 +119,9 @@ AGX_API int agx_ntt_plan_create(agx_ntt_plan** plan, uint32_t n, uint32_t num_pr
 AGX_API int agx_ntt_plan_create_auto(agx_ntt_plan** plan, uint32_t n, uint32_t num_primes,
                              const uint64_t* moduli, const uint64_t* psi);
 AGX_API int agx_ntt_plan_destroy(agx_ntt_plan* plan);
-AGX_API int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant); /* testing / benchmarking only */
+/* testing / benchmarking only.  NOT thread-safe: it rebuilds the plan's pass tables, so no launch that uses the plan may be in flight */
+/* or be issued from another thread while it runs (it synchronises the device before it frees the old tables)                         */
+AGX_API int agx_ntt_plan_set_variant(agx_ntt_plan* plan, int variant);
 AGX_API int agx_ntt_plan_info(const agx_ntt_plan* plan, uint32_t* n, uint32_t* num_primes, int* device, int* has_inverse);
 AGX_API int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_index, uint64_t* q, uint64_t* psi);
 
@@ -122,7 +129,10 @@ AGX_API int agx_ntt_plan_get_modulus(const agx_ntt_plan* plan, uint32_t prime_in
 /* (3) Device-pointer batched transforms.  Frame (p, b) starts at              */
 /* base + p*prime_stride + b*poly_stride (strides in uint64_t elements);       */
 /* the dense forms use the [prime][batch][n] layout (prime_stride = batch*n,   */
-/* poly_stride = n).  In place (d_out == d_in) is allowed.  Asynchronous on    */
+/* poly_stride = n).  In place (d_out == d_in) is allowed; an output whose     */
+/* frames touch the input's frames without being the same frames (d_out =      */
+/* d_in + n/2, c = a + 8 ...) returns AGX_ERR_BAD_ARGUMENT: workgroups run in  */
+/* any order, so such a call would corrupt its own inputs.  Asynchronous on    */
 /* `stream`; nothing is allocated or synchronised inside, so the calls can be  */
 /* captured into a hipGraph (kernels that hand out frames through a counter    */
 /* switch to a stateless form while the stream is capturing).                   */
@@ -141,10 +151,10 @@ AGX_API int agx_ntt_inverse_strided(const agx_ntt_plan* plan, const uint64_t* d_
 /* c = a o b (coefficient-wise product mod q_p), dense [prime][batch][n] layout; c may alias a or b */
 AGX_API int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                       uint64_t batch, void* stream);
-/* c = a * b in Z_q[X]/(X^n + 1) = INTT(NTT(a) o NTT(b)); dense layout; c may alias a or b.
- * d_scratch: num_primes*batch*n elements of device memory owned by the caller, distinct from a, b, c.
- * It is only used when n has no one-launch fused kernel -- today n < 1024 (and plans forced onto the radix-2 kernels) -- and
- * may be NULL otherwise (1024 <= n <= 32768); a NULL scratch where one is needed returns AGX_ERR_NULL_POINTER. */
+/* c = a * b in Z_q[X]/(X^n + 1) = INTT(NTT(a) o NTT(b)); dense layout; c may alias a, b or both (squaring in place: a == b == c).
+ * d_scratch: num_primes*batch*n elements of device memory owned by the caller, disjoint from a, b, c.
+ * It is only used when n has no one-launch fused kernel -- today n < 32 (and plans forced onto the radix-2 kernels) -- and
+ * may be NULL otherwise (32 <= n <= 32768); a NULL scratch where one is needed returns AGX_ERR_NULL_POINTER. */
 AGX_API int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                     uint64_t* d_scratch, uint64_t batch, void* stream);
 
@@ -162,6 +172,52 @@ AGX_API int agx_ntt_find_primes(uint32_t bits, uint32_t n, uint32_t count, uint6
 AGX_API int agx_ntt_min_root(uint64_t q, uint32_t n, uint64_t* psi_out);
 AGX_API int agx_ntt_make_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* twiddles, uint64_t* precons);
 AGX_API int agx_ntt_make_inverse_tables(uint64_t q, uint64_t psi, uint32_t n, uint64_t* inv_twiddles, uint64_t* inv_precons);
+
+/* ------------------------------------------------------------------------- */
+/* (5) Groups: the same calls over several GPUs of one node.                    */
+/* The reference deals the frames of a call to its replicated compute units     */
+/* inside the call: unit i gets floor(F / C) + [i < F mod C] frames             */
+/* (src/kernel/ntt.cpp:526-536), frame b goes to unit b % C (:579-582) and is   */
+/* collected from it (:622-625); units never exchange data.  A group is that    */
+/* scheme over whole devices: one SHARD per entry of `devices` (a device may be */
+/* listed more than once), each with its own plan (tables prepared once on the  */
+/* host), stream, staging buffers and host thread.  Frames are dealt in          */
+/* CONTIGUOUS blocks of the reference's minibatch sizes (agx_ntt_shard_range).   */
+/* No collective, no peer access: nothing is exchanged between shards.           */
+/* A bad device id returns AGX_ERR_BAD_ARGUMENT; a call's status is that of the  */
+/* lowest-numbered failing shard.  One call at a time per group (calls from      */
+/* several host threads serialise).                                               */
+/* ------------------------------------------------------------------------- */
+typedef struct agx_ntt_group agx_ntt_group;
+
+/* block of shard `index` when num_frames frames are dealt to num_shards shards: pure arithmetic, no device needed */
+AGX_API int agx_ntt_shard_range(uint64_t num_frames, uint32_t num_shards, uint32_t index, uint64_t* first, uint64_t* count);
+
+/* arguments after num_devices as agx_ntt_plan_create / agx_ntt_plan_create_auto */
+AGX_API int agx_ntt_group_create(agx_ntt_group** group, const int* devices, uint32_t num_devices, uint32_t n, uint32_t num_primes,
+                                 const uint64_t* moduli, const uint64_t* twiddles, const uint64_t* precons,
+                                 const uint64_t* inv_twiddles, const uint64_t* inv_precons);
+AGX_API int agx_ntt_group_create_auto(agx_ntt_group** group, const int* devices, uint32_t num_devices, uint32_t n, uint32_t num_primes,
+                                      const uint64_t* moduli, const uint64_t* psi);
+AGX_API int agx_ntt_group_destroy(agx_ntt_group* group);
+AGX_API int agx_ntt_group_info(const agx_ntt_group* group, uint32_t* num_shards, uint32_t* n, uint32_t* num_primes);
+/* shard `index`: its device, its plan (owned by the group) and its stream (a hipStream_t: record events on it to time a shard) */
+AGX_API int agx_ntt_group_shard(const agx_ntt_group* group, uint32_t index, int* device, agx_ntt_plan** plan, void** stream);
+
+/* host frames (one modulus): agx_ntt_forward_host_stream / agx_ntt_inverse_host_stream on every shard's block at once, each shard */
+/* from its own host thread through its own three-slot pipeline; synchronous                                                       */
+AGX_API int agx_ntt_group_forward_host(const agx_ntt_group* group, const uint64_t* in, const uint64_t* in2, uint64_t* out, uint64_t num_frames);
+AGX_API int agx_ntt_group_inverse_host(const agx_ntt_group* group, const uint64_t* in, uint64_t* out, uint64_t num_frames);
+
+/* device pointers: arrays with one entry per shard -- d_in[i] / d_out[i] live on shard i's device in the dense [prime][batch[i]][n] */
+/* layout.  Every shard is launched from its own host thread on its own stream; the call returns when every launch has been queued  */
+/* (asynchronous like agx_ntt_forward); agx_ntt_group_synchronize waits for all shards' streams.                                    */
+AGX_API int agx_ntt_group_forward(const agx_ntt_group* group, const uint64_t* const* d_in, uint64_t* const* d_out, const uint64_t* batch);
+AGX_API int agx_ntt_group_inverse(const agx_ntt_group* group, const uint64_t* const* d_in, uint64_t* const* d_out, const uint64_t* batch);
+/* d_scratch may be NULL (or hold NULL entries) wherever agx_ntt_polymul accepts a NULL scratch */
+AGX_API int agx_ntt_group_polymul(const agx_ntt_group* group, const uint64_t* const* d_a, const uint64_t* const* d_b, uint64_t* const* d_c,
+                                  uint64_t* const* d_scratch, const uint64_t* batch);
+AGX_API int agx_ntt_group_synchronize(const agx_ntt_group* group);
 
 #ifdef __cplusplus
 }

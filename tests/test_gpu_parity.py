@@ -17,7 +17,8 @@ ALL_SIZES = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 
 # registry ids of the product library (what a default or a call-shape selector can reach); every other id is an A/B entry that
 # only lib/libagxntt_diag.so carries: tests/test_gpu_diag.py re-runs the id-parametrised tests of this file in a child process
 # bound to that library
-PRODUCT_IDS = {93, 92, 91, 159, 164, 117, 119, 120, 121, 122, 123} | set(range(150, 159)) | set(range(130, 142))
+PRODUCT_IDS = ({93, 92, 91, 159, 164, 117, 119, 120, 121, 122, 123} | set(range(150, 159)) | set(range(130, 142))
+               | set(range(200, 215)) | set(range(230, 235)) | set(range(240, 245)))
 
 
 def _select(agx, plan, config):
@@ -53,8 +54,8 @@ def _oracle_forward_rns(orc, x, tabs, n, batch):
 @pytest.mark.parametrize("variant", ["radix2", "regblock"])
 @pytest.mark.parametrize("n", ALL_SIZES)
 def test_forward_bit_exact(agx, orc, dev, n, variant):
-    if variant == "regblock" and n < 1024:
-        pytest.skip("register-blocked kernels start at n=1024")
+    if variant == "regblock" and n < 32:
+        pytest.skip("register-blocked kernels start at n=32 (wave-packed kernels, csrc/wp_kernels.hpp)")
     bits = 30 if n == 1024 else (61 if n in (8, 8192) else 60)
     batch = 5 if n <= 4096 else 3          # ragged: not a multiple of polys-per-block
     primes = 2 if n <= 8192 else 1
@@ -483,8 +484,8 @@ def test_empty_batch_and_errors(agx, dev):
     with pytest.raises(agx.AgxError) as ei:
         fwd_only.inverse(d.data_ptr(), d.data_ptr(), 1, dev.stream)
     assert ei.value.status == 9
-    # poly-mul: a size without a one-launch kernel (n < 1024) needs caller scratch (NULL -> 1), scratch must be distinct (-> 5)
-    big = agx.Plan(512, [agx.find_primes(60, 512)[0]])
+    # poly-mul: a size without a one-launch kernel (n < 32) needs caller scratch (NULL -> 1), scratch must be distinct (-> 5)
+    big = agx.Plan(16, [agx.find_primes(60, 16)[0]])
     e = dev.empty(512)
     for scratch, status in ((0, 1), (e.data_ptr(), 5)):
         with pytest.raises(agx.AgxError) as ei:
@@ -779,6 +780,10 @@ REGISTRY = [
     # 32-bit arithmetic: tier 2 (every q < 2^30), tier 1 (every q < 2^31)
     (130, 1024, 30), (131, 2048, 30), (132, 4096, 30), (133, 8192, 30), (134, 16384, 30), (135, 32768, 30),
     (136, 1024, 31), (137, 2048, 31), (138, 4096, 31), (139, 8192, 31), (140, 16384, 31), (141, 32768, 31),
+    # wave-packed kernels of n = 32 ... 512 (csrc/wp_kernels.hpp): 16q-lazy / fast / exact per size, then the 32-bit tiers
+    (200, 32, 60), (201, 32, 61), (202, 32, 62), (203, 64, 60), (204, 64, 61), (205, 64, 62), (206, 128, 60), (207, 128, 61), (208, 128, 62),
+    (209, 256, 60), (210, 256, 61), (211, 256, 62), (212, 512, 60), (213, 512, 61), (214, 512, 62),
+    (230, 32, 30), (231, 64, 30), (232, 128, 30), (233, 256, 30), (234, 512, 30), (240, 32, 31), (241, 64, 31), (242, 128, 31), (243, 256, 31), (244, 512, 31),
 ]
 
 
@@ -809,6 +814,132 @@ def test_every_registry_entry_at_its_own_size(agx, orc, dev, config, n, max_bits
         wantc = np.concatenate([_oracle_polymul(orc, a[f * n:(f + 1) * n], b[f * n:(f + 1) * n], q, psi, n) for f in range(batch)])
         assert np.array_equal(dev.to_host(d_c), wantc), (config, bits, "polymul")
         plan.close()
+
+
+SMALL_SIZES = [32, 64, 128, 256, 512]
+
+
+@pytest.mark.parametrize("bits", [60, 61, 62, 31, 30, 20])
+@pytest.mark.parametrize("n", SMALL_SIZES)
+def test_wave_packed_small_sizes(agx, orc, dev, n, bits):
+    """n = 32 ... 512 (n = 32 is in the reference's size table, include/kernel/ntt.h:11-12): several frames share a wave
+    (csrc/wp_kernels.hpp), so the frame counts here straddle the frames-per-wave and frames-per-workgroup boundaries (a wave whose
+    last frames do not exist folds them back for loads and masks their stores).  Forward out of place and in place on inputs in
+    [0,4q), lazy outputs, inverse on arbitrary data, extreme coefficients, the one-launch product with every aliasing and NO scratch
+    -- all against the oracle, for every arithmetic form (16q-lazy / fast / exact, 32-bit tier 1 / tier 2)."""
+    primes = 2
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
+    rng = np.random.default_rng(n * 7 + bits)
+    for batch in (1, 3, 17, 64, 67, 259):
+        hi = 4 if bits < 62 else 3
+        x = np.concatenate([rand_coeffs(rng, batch * n, t[0], hi_mult=hi) for t in tabs])
+        # extreme coefficients in the first frames: 0, q-1, 4q-1 (the top of the lazy input range)
+        for p, t in enumerate(tabs):
+            x[p * batch * n:p * batch * n + n:3] = np.uint64(t[0] - 1)
+            if batch > 1:
+                x[(p * batch + 1) * n:(p * batch + 2) * n:2] = np.uint64(hi * t[0] - 1)
+        want = _oracle_forward_rns(orc, x, tabs, n, batch)
+        d_x, d_y = dev.to_device(x), dev.empty(x.size)
+        plan.forward(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+        assert np.array_equal(dev.to_host(d_y), want), (n, bits, batch, "forward out of place")
+        assert np.array_equal(dev.to_host(d_x), x), "input must not be modified"
+        plan.forward_lazy(d_x.data_ptr(), d_y.data_ptr(), batch, dev.stream)
+        y = dev.to_host(d_y)
+        for p, t in enumerate(tabs):
+            sl = slice(p * batch * n, (p + 1) * batch * n)
+            assert (y[sl].astype(object) < 4 * t[0]).all()
+            assert np.array_equal(y[sl] % np.uint64(t[0]), want[sl]), (n, bits, batch, "lazy")
+        plan.inverse(d_y.data_ptr(), d_y.data_ptr(), batch, dev.stream)      # lazy values are legal inverse inputs
+        xr = np.concatenate([x[p * batch * n:(p + 1) * batch * n] % np.uint64(t[0]) for p, t in enumerate(tabs)])
+        assert np.array_equal(dev.to_host(d_y), xr), (n, bits, batch, "round trip")
+        plan.forward(d_x.data_ptr(), d_x.data_ptr(), batch, dev.stream)
+        assert np.array_equal(dev.to_host(d_x), want), (n, bits, batch, "forward in place")
+        # inverse of arbitrary (not forward-image) data against the oracle's definitional inverse
+        r = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+        d_r, d_z = dev.to_device(r), dev.empty(r.size)
+        plan.inverse(d_r.data_ptr(), d_z.data_ptr(), batch, dev.stream)
+        wanti = np.concatenate([orc.inverse(r[p * batch * n:(p + 1) * batch * n], t[0], orc.make_inv_tables(t[0], t[1], n)[0], n) for p, t in enumerate(tabs)])
+        assert np.array_equal(dev.to_host(d_z), wanti), (n, bits, batch, "inverse")
+    # one-launch product, scratch = NULL: c distinct, c = a, c = b, squaring with and without aliasing
+    batch = 21
+    a = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+    b = np.concatenate([rand_coeffs(rng, batch * n, t[0]) for t in tabs])
+
+    def product(u, v):
+        return np.concatenate([_oracle_polymul(orc, u[(p * batch + f) * n:(p * batch + f + 1) * n], v[(p * batch + f) * n:(p * batch + f + 1) * n], t[0], t[1], n)
+                               for p, t in enumerate(tabs) for f in range(batch)])
+
+    want_ab, want_aa = product(a, b), product(a, a)
+    d_a, d_b, d_c = dev.to_device(a), dev.to_device(b), dev.empty(a.size)
+    plan.polymul(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_c), want_ab), (n, bits, "product")
+    plan.polymul(d_a.data_ptr(), d_a.data_ptr(), d_c.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_c), want_aa), (n, bits, "square")
+    d_t = dev.to_device(a)
+    plan.polymul(d_t.data_ptr(), d_b.data_ptr(), d_t.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_t), want_ab), (n, bits, "c = a")
+    d_t = dev.to_device(b)
+    plan.polymul(d_a.data_ptr(), d_t.data_ptr(), d_t.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_t), want_ab), (n, bits, "c = b")
+    d_t = dev.to_device(a)
+    plan.polymul(d_t.data_ptr(), d_t.data_ptr(), d_t.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_t), want_aa), (n, bits, "square in place")
+    if n <= 128:      # against the definition too
+        sl = slice(0, n)
+        assert np.array_equal(want_ab[sl], orc.schoolbook(a[sl], b[sl], tabs[0][0], n))
+    plan.close()
+
+
+@pytest.mark.parametrize("n", SMALL_SIZES)
+def test_wave_packed_strided_layouts(agx, orc, dev, n):
+    """[poly][prime][n] callers at the small sizes (prime_stride = n, poly_stride = P n: the frames of a wave are NOT adjacent), and a
+    padded dense layout (poly_stride = n + 8), forward and inverse, 60- and 30-bit moduli"""
+    for bits in (60, 30):
+        batch, primes = 37, 3
+        plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes)
+        rng = np.random.default_rng(n + bits)
+        x = np.empty((batch, primes, n), dtype=np.uint64)
+        for p in range(primes):
+            x[:, p, :] = rand_coeffs(rng, batch * n, tabs[p][0]).reshape(batch, n)
+        d = dev.to_device(x.reshape(-1))
+        plan.forward_strided(d.data_ptr(), d.data_ptr(), batch, n, primes * n, dev.stream)
+        y = dev.to_host(d).reshape(batch, primes, n)
+        for p, (q, _, tw, pre) in enumerate(tabs):
+            assert np.array_equal(y[:, p, :].reshape(-1), orc.forward(np.ascontiguousarray(x[:, p, :]).reshape(-1), q, tw, pre, n)), (n, bits, p)
+        plan.inverse_strided(d.data_ptr(), d.data_ptr(), batch, n, primes * n, dev.stream)
+        assert np.array_equal(dev.to_host(d).reshape(batch, primes, n), x)
+        # padded frames: poly_stride = n + 8, prime_stride = batch (n + 8); the pad words must come back untouched
+        pad = n + 8
+        z = np.full((primes, batch, pad), 0xDEADBEEFCAFEF00D, dtype=np.uint64)
+        for p in range(primes):
+            z[p, :, :n] = x[:, p, :]
+        d = dev.to_device(z.reshape(-1))
+        plan.forward_strided(d.data_ptr(), d.data_ptr(), batch, batch * pad, pad, dev.stream)
+        got = dev.to_host(d).reshape(primes, batch, pad)
+        assert (got[:, :, n:] == np.uint64(0xDEADBEEFCAFEF00D)).all()
+        for p in range(primes):
+            assert np.array_equal(got[p, :, :n], y[:, p, :])
+        plan.close()
+
+
+@pytest.mark.parametrize("bits", [60, 61, 62, 30])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 32768])
+def test_polymul_squaring_with_and_without_aliasing(agx, orc, dev, n, bits):
+    """agx_ntt_polymul(a, a, c) and (a, a, a) (the parked product read its own parked transform back as the second
+    operand when a == b == c; squaring now has its own kernel there); against the oracle's product"""
+    batch = 3
+    plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, 1)
+    q, psi = tabs[0][0], tabs[0][1]
+    rng = np.random.default_rng(n + bits + 99)
+    a = rand_coeffs(rng, batch * n, q)
+    want = np.concatenate([_oracle_polymul(orc, a[f * n:(f + 1) * n], a[f * n:(f + 1) * n], q, psi, n) for f in range(batch)])
+    d_a, d_c = dev.to_device(a), dev.empty(a.size)
+    plan.polymul(d_a.data_ptr(), d_a.data_ptr(), d_c.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_c), want), (n, bits, "a == b, c distinct")
+    assert np.array_equal(dev.to_host(d_a), a)
+    plan.polymul(d_a.data_ptr(), d_a.data_ptr(), d_a.data_ptr(), 0, batch, dev.stream)
+    assert np.array_equal(dev.to_host(d_a), want), (n, bits, "a == b == c")
+    plan.close()
 
 
 @pytest.mark.parametrize("config,n,batch", [(117, 16384, 333), (119, 32768, 290), (118, 16384, 333), (116, 32768, 290), (43, 16384, 333), (57, 16384, 333), (37, 16384, 333)])
