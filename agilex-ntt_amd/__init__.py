@@ -142,7 +142,7 @@ def kernel_source_sha16():
     import hashlib
 
     h = hashlib.sha256()
-    files = glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + [os.path.join(_HERE, "csrc", f) for f in ("rb_kernels.hpp", "rb32_kernels.hpp", "rb_stream_opts.hpp", "rb_registry.hpp", "modarith.hpp", "ntt_kernels.hpp")]
+    files = glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + [os.path.join(_HERE, "csrc", f) for f in ("rb_frame.hpp", "rb_kernels.hpp", "rb32_kernels.hpp", "wp_kernels.hpp", "rb_stream_opts.hpp", "rb_registry.hpp", "modarith.hpp", "ntt_kernels.hpp")]
     for f in sorted(files):
         h.update(os.path.relpath(f, _HERE).encode())
         h.update(open(f, "rb").read())

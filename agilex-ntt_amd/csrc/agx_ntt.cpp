@@ -275,7 +275,7 @@ int check_call(const agx_ntt_plan* plan, const void* a, const void* b, uint64_t 
     if (hipGetDevice(&dev) != hipSuccess || dev != plan->device) return AGX_ERR_BAD_ARGUMENT;   // the plan's tables live on plan->device
     if (prime_stride < 0 || poly_stride < 0) return AGX_ERR_BAD_ARGUMENT;
     if (batch > 1 && poly_stride < (int64_t)plan->n) return AGX_ERR_BAD_ARGUMENT;   // frames would overlap
-    if ((batch << (plan->log_n > 14 ? plan->log_n - 14 : 0)) > 0x7fffffffull) return AGX_ERR_BAD_ARGUMENT;  // grid.x limit
+    if ((batch << (plan->log_n > 14 ? plan->log_n - 14 : 0)) > 0x7fffffffull) return AGX_ERR_BAD_ARGUMENT;  // grid.x limit (the radix-2 kernels split n = 32768 in two blocks)
     if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 7u) != 0) return AGX_ERR_BAD_ARGUMENT;      // uint64_t data
     if (partial_overlap(a, b, plan->n, plan->num_primes, batch, prime_stride, poly_stride)) return AGX_ERR_BAD_ARGUMENT;
     return AGX_OK;

@@ -8,7 +8,7 @@
 //    for the inverse transform.
 //  * register-blocked kernels: every thread keeps 2^R coefficients in VGPRs and runs R
 //    butterfly stages per pass with no memory traffic; passes exchange through one padded
-//    LDS slab.  This is the throughput path (n >= 1024).
+//    LDS slab.  This is the throughput path (n >= 32; their registry is rb_registry.hpp).
 //
 // No MFMA: this is 64-bit integer modular arithmetic (v_mad_u64_u32 / v_mul_hi_u32), bounded
 // by VALU integer multiply issue and HBM bandwidth.
@@ -23,6 +23,8 @@
 namespace agx {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char agx_dyn_lds[];
+
+static constexpr int kMaxLdsLog = 14;  // radix-2 kernels: 16384 coefficients = 128 KiB of the CU's 160 KiB LDS; n = 32768 runs as two blocks + one global stage
 
 // ---------------------------------------------------------------------------------------
 // radix-2 forward, LDS resident.  Block = one sub-transform of 2^nb_log coefficients:
@@ -220,7 +222,7 @@ void for_each_entry(F&& f) {
     const rb_span groups[] = {rb_entries_n4096(), rb_entries_s1024(), rb_entries_s2048(), rb_entries_s4096(), rb_entries_s8192(), rb_entries_s16384(), rb_entries_s32768(),
                               rb_entries_q32a(), rb_entries_q32b(), rb_entries_wp(), rb_entries_wp32(),
 #ifdef AGX_DIAG
-                              rb_entries_n1024(), rb_entries_n2048(), rb_entries_n8192(), rb_entries_n4096_ab(), rb_entries_n8192_split(), rb_entries_n8192_pair(), rb_entries_n16384(), rb_entries_gen1(), rb_entries_diag(),
+                              rb_entries_diag(),
 #endif
     };
     for (const rb_span& g : groups)
@@ -252,20 +254,12 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int 
     int log_n = 0;
     while ((1u << log_n) < n) ++log_n;
     if (log_n < 5) return rb;  // n < 32 stays on the radix-2 kernel
-    // an entry serves n if its resident size plus its (fixed or default) number of split stages is log_n
-    auto split_for = [&](const rb_entry& e) -> int {
-        if (e.fused_split > 0) return e.log_local + e.fused_split == log_n ? e.fused_split : -1;
-        if (e.log_local == log_n) return 0;      // whole frame resident (n = 32768: split-word image)
-        if (e.whole_only) return -1;
-        const int split = log_n > kMaxLdsLog ? log_n - kMaxLdsLog : 0;
-        return e.log_local + split == log_n ? split : -1;
-    };
     // a 32-bit entry is legal when every modulus fits its tier and the tables honour the precon contract
     auto legal = [&](const rb_entry& c) { return c.arith <= arith_level && (c.narrow == 0 || (arith_level >= 1 && narrow_level >= (c.narrow == 2 ? 2 : 1))); };
     const rb_entry* e = nullptr;
     if (config_id >= 0) {
         e = rb_lookup(config_id);
-        if (e && (split_for(*e) < 0 || !legal(*e))) e = nullptr;
+        if (e && (e->log_n != log_n || !legal(*e))) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
         static const int kDefaults[] = {230, 231, 232, 233, 234, 240, 241, 242, 243, 244,                 // n = 32 ... 512, narrow moduli: wave-packed 32-bit kernels (tier 2, then tier 1)
@@ -276,16 +270,14 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int 
                                         119, 117, 121, 120, 123, 122};                                  // n = 32768 / 16384
         for (int id : kDefaults) {
             const rb_entry* c = rb_lookup(id);
-            if (c && split_for(*c) >= 0 && legal(*c)) { e = c; break; }
+            if (c && c->log_n == log_n && legal(*c)) { e = c; break; }
         }
     }
     if (!e) return rb;
     rb.config_id = e->id;
     rb.log_n = log_n;
-    rb.log_split = split_for(*e);
-    rb.log_local = e->log_local;
     rb.r = e->r;
-    rb.pairs_per_prime = e->table_pairs << rb.log_split;
+    rb.pairs_per_prime = e->table_pairs;
     return rb;
 }
 
@@ -349,18 +341,9 @@ hipError_t launch_inverse_radix2(const plan_view& pv, const uint64_t* in, uint64
 }
 
 hipError_t launch_forward_regblock(const plan_view& pv, const uint64_t* in, uint64_t* out, const frame_layout& fl, hipStream_t s) {
-    if (!pv.rb.valid()) return hipErrorInvalidValue;
-    const rb_entry* e = rb_lookup(pv.rb.config_id);
+    const rb_entry* e = pv.rb.valid() ? rb_lookup(pv.rb.config_id) : nullptr;
     if (!e) return hipErrorInvalidValue;
-    if (e->fused_split > 0 && (in != out || e->fused_in_place_ok)) return e->launch_fused(pv, in, out, fl, s);
-    const uint64_t* src = in;
-    for (int st = 0; st < pv.rb.log_split; ++st) {
-        dim3 grid(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);
-        hipLaunchKernelGGL(fwd_global_stage, grid, dim3(256), 0, s, src, out, pv.consts, pv.tw, pv.log_n, (uint32_t)st, fl.batch,
-                           fl.prime_stride, fl.poly_stride);
-        src = out;
-    }
-    return e->launch(pv, src, out, fl, s);
+    return e->launch(pv, in, out, fl, s);
 }
 
 bool regblock_has_inverse(const regblock_layout& rb) {
@@ -370,28 +353,18 @@ bool regblock_has_inverse(const regblock_layout& rb) {
 
 bool regblock_has_polymul(const regblock_layout& rb) {
     const rb_entry* e = rb_lookup(rb.config_id);
-    // 2^14: 1024 threads x 128 VGPRs cannot hold two frames, unless the kernel parks one of them in c's frame
-    return e && e->launch_mul && rb.log_split == 0 && (rb.log_local <= 13 || e->mul_parked);
+    return e && e->launch_mul;
 }
 
 hipError_t launch_inverse_regblock(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     const rb_entry* e = rb_lookup(pv.rb.config_id);
     if (!e || !e->launch_inv || !pv.itw_rb) return hipErrorInvalidValue;
-    if (pv.rb.log_split == 1 && e->launch_inv_pair) return e->launch_inv_pair(pv, in, in2, out, fl, s);
-    if (pv.rb.log_split == 0 && e->launch_inv_loop) return e->launch_inv_loop(pv, in, in2, out, fl, s);
-    hipError_t err = e->launch_inv(pv, in, in2, out, fl, s);
-    if (err != hipSuccess) return err;
-    for (int st = pv.rb.log_split - 1; st >= 0; --st) {   // stages with a gap wider than the resident block
-        dim3 g2(grid_1d(fl.batch << (pv.log_n - 1), 256), pv.num_primes);
-        hipLaunchKernelGGL(inv_global_stage, g2, dim3(256), 0, s, out, pv.consts, pv.itw, pv.log_n, (uint32_t)st, fl.batch,
-                           fl.prime_stride, fl.poly_stride);
-    }
-    return hipGetLastError();
+    return e->launch_inv(pv, in, in2, out, fl, s);
 }
 
 hipError_t launch_polymul_regblock(const plan_view& pv, const uint64_t* a, const uint64_t* b, uint64_t* c, const frame_layout& fl, hipStream_t s) {
     const rb_entry* e = rb_lookup(pv.rb.config_id);
-    if (!e || !e->launch_mul || !pv.itw_rb || pv.rb.log_split != 0) return hipErrorInvalidValue;
+    if (!e || !e->launch_mul || !pv.itw_rb) return hipErrorInvalidValue;
     return e->launch_mul(pv, a, b, c, fl, s);
 }
 

@@ -17,9 +17,7 @@ struct prime_consts {           // one per prime, device array
 
 // geometry of one register-blocked configuration (compile-time L, R mirrored at run time)
 struct regblock_layout {
-    int log_n = 0;       // whole transform
-    int log_local = 0;   // sub-transform handled by one workgroup (log_n - log_split)
-    int log_split = 0;   // leading stages done by the global split kernel
+    int log_n = 0;       // whole transform = the frame one workgroup (or one wave's group of lanes) holds
     int r = 0;           // log2 coefficients per thread
     int config_id = -1;  // entry of the kernel registry in ntt_kernels.hip
     uint32_t pairs_per_prime = 0;  // table length per prime, in {w,w'} pairs

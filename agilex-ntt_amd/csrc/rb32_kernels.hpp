@@ -372,7 +372,7 @@ void build_table32_t(const regblock_layout&, const uint64_t* tw, const uint64_t*
             const uint32_t m_local = 1u << (L - 1 - b);
             for (int h = 0; h < H; ++h) {
                 const uint32_t idx = m_local + ((uint32_t)h << k) + (uint32_t)o;      // natural twiddle index m + i (ntt.cpp:298-300)
-                const size_t at = rlo >= 6 ? (size_t)h * G::C + j : (size_t)j * H + h;
+                const size_t at = rb2_geom<L, R>::uniform_pass(p) ? (size_t)h * G::C + j : (size_t)j * H + h;
                 tp[at] = make_uint2((uint32_t)tw[idx], (uint32_t)(pre[idx] >> 32));
             }
         }
@@ -429,12 +429,10 @@ hipError_t init_q32_t() {
 // TIER 2 needs every modulus below 2^30, TIER 1 below 2^31 (rb_entry::narrow); the tables must honour the precon contract (arith >= 1)
 template <int L, int R, int PPB, int TIER, int MINW>
 constexpr rb_entry make_entry_q32(int id) {
-    rb_entry e{id, L, R, PPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs / 2, q32_lds_bytes<L, R, PPB>(),
+    rb_entry e{id, L, R, PPB, MINW, (uint32_t)rb_geom<L, R>::table_pairs / 2, q32_lds_bytes<L, R, PPB>(),
                &build_table32_t<L, R>, &launch_q32_t<L, R, PPB, TIER, MINW>, &init_q32_t<L, R, PPB, TIER, MINW>, 1,
-               &launch_inv_q32_t<L, R, PPB, TIER, MINW>, &launch_mul_q32_t<L, R, PPB, TIER, MINW>, 0, nullptr, false};
-    e.mul_parked = true;      // the fused product is legal at every size (both frames are 2^(R+1) VGPRs)
+               &launch_inv_q32_t<L, R, PPB, TIER, MINW>, &launch_mul_q32_t<L, R, PPB, TIER, MINW>};
     e.narrow = TIER;
-    e.whole_only = true;      // no split_log support: the whole frame is resident at every size
     return e;
 }
 

@@ -1,28 +1,14 @@
-// reg_diag.hip -- diagnostics and A/B kernels, built only into lib/libagxntt_diag.so (make diag, -DAGX_DIAG):
-// the trace twin of the default n=4096 kernel (70: s_memtime stamps at 12 phase boundaries, tools/timeline.py),
-// the streaming kernels (83/84: resident workgroups drawing frames from a ticket counter; their ticket pair belongs
-// to the plan, so ONE stream per plan), and with -DAGX_TIMING_ABLATIONS the timing-only ablations (67-72, WRONG results).
-// None of this is in the product library.
+// reg_diag.hip -- lib/libagxntt_diag.so only (make diag, -DAGX_DIAG): the trace twin of the n = 4096 default.  tools/timeline.py
+// selects it (AGX_VARIANT_REGBLOCK_BASE + 70) and reads the s_memtime stamps every wave leaves at twelve phase boundaries
+// (agx_ntt_debug_set_trace_buffer, tools/agx_ntt_diag.h); forward and inverse.  The streaming / ablation / priority-policy A/B kernels
+// that used to live here were measured, recorded (profiles/r01g_*, r01j_*, r03_*) and removed in round 4.
 #define AGX_TU tu_diag
 #include "rb_kernels.hpp"
 
 namespace agx {
 namespace AGX_TU {
 const rb_entry kEntries[] = {
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptTrace) << 1), 8>(70),   // diagnostics only: id 90 + stamps (forward and inverse)
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptTrace | kOptInvTwFirst) << 1), 8>(73),   // + the inverse's first-stage twiddles ahead of the staging
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptTrace | kOptInvTwFirst | kOptInvTwFirstAll) << 1), 8>(74),
-    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 6>(83),   // A/B only: one stream per plan
-    make_entry_stream<12, 3, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptNtLoad | kOptNtStore) << 1), 8, 1>(84),
-#ifdef AGX_TIMING_ABLATIONS
-    // timing only, WRONG RESULTS (make EXTRA=-DAGX_TIMING_ABLATIONS): the default kernel without per-lane twiddle
-    // traffic (67), with L2-resident frames (68: loads and stores, 71: loads only, 72: stores only), with neither (69)
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptAblateTw) << 1), 8>(67),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptAblateHbm) << 1), 8>(68),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptAblateTw | kOptAblateHbm) << 1), 8>(69),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptAblateHbm | kOptAblateLdOnly) << 1), 8>(71),
-    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptAblateHbm | kOptAblateStOnly) << 1), 8>(72),
-#endif
+    make_entry2<12, 3, 1, 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptTwAhead | kOptPrio | kOptPrioBarrier | kOptScalarBase | kOptLazyInv | kOptTwAheadInv | kOptNtLoad | kOptNtStore | kOptTrace) << 1), 8>(70),
 };
 }  // namespace AGX_TU
 

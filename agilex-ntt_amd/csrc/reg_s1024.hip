@@ -25,11 +25,6 @@ const rb_entry kEntries[] = {
     make_entry_single_mul2<10, 4, kLazy, 5, 4>(150),
     make_entry_single_mul2<10, 4, kFast, 5, 4>(151),
     make_entry_single_mul2<10, 4, kExact, 5, 4>(152),
-#ifdef AGX_DIAG
-    // A/B: the parked product (129) and six waves per SIMD (149)
-    make_entry_single<10, 4, kLazy, 5>(129),
-    make_entry_single<10, 4, kLazy, 6>(149),
-#endif
 };
 }  // namespace AGX_TU
 

@@ -8,17 +8,11 @@ namespace agx {
 namespace AGX_TU {
 const rb_entry kEntries[] = {
     // n = 32768: 1024 threads, the whole frame resident (136 KiB image); inverse by the ticket-drawing loop kernel (+9 % at 8,192 frames)
-    make_entry_single_dloop<15, 5, kLazy, 4, false, true>(119),
+    make_entry_single_invloop<15, 5, kLazy, 4>(119),
     make_entry_single<15, 5, kFast, 4>(121),
     make_entry_single<15, 5, kExact, 4>(123),
 #ifdef AGX_DIAG
-    // A/B: inverse one workgroup per frame too (114); forward by the loop kernel as well (116: 52 B of scratch, -6 %); 125 frame loads at raised priority (nothing)
-    make_entry_single<15, 5, kLazy, 4>(114),
-    make_entry_single_dloop<15, 5, kLazy, 4, true, true>(116),
-    make_entry_single<15, 5, kLazy | (kOptPrio << 1), 4>(125),
-    // A/B: forward by the ticket loop with one table entry per chunk (120 VGPRs, no scratch): still -4 % (n = 16384) / -3..-5 % (n = 32768) against one
-    // workgroup per frame -- the hand-over barrier and the thinner twiddle prefetch cost more than the overlapped store tail wins
-    make_entry_single_dloop<15, 5, kLazy | (kOptStreamCh1 << 1), 4, true, true>(146),
+    make_entry_single<15, 5, kLazy, 4>(114),      // A/B twin: the inverse one workgroup per frame too
 #endif
 };
 }  // namespace AGX_TU

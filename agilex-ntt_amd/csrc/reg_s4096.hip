@@ -12,13 +12,10 @@ const rb_entry kEntries[] = {
     // product (-4 %) lose to id 93's, so only the forward kernel ships (A/B twin with all three transforms: id 147)
     make_entry_single_fwd<12, 5, kLazy | (kOptPrio << 1), 4>(159),
 #ifdef AGX_DIAG
-    // A/B: all three transforms in this shape without (127) and with (147) the load priority; 148 = 147 with the priority held through the barrier
-    make_entry_single<12, 5, kLazy, 4>(127),
+    // A/B twins kept in lib/libagxntt_diag.so: all three transforms in this shape with the load priority (147: its inverse -1 %, its parked
+    // product -4 % against id 93's), and R = 4 streamed one table entry at a time at 8 waves/SIMD (161: equal to the default within 1 %)
     make_entry_single<12, 5, kLazy | (kOptPrio << 1), 4>(147),
-    make_entry_single<12, 5, kLazy | ((kOptPrio | kOptPrioBarrier) << 1), 4>(148),
-    // A/B: R = 4 (16 coefficients per thread) streamed with one table entry per chunk: 60-64 VGPRs, no scratch -> 8 waves/SIMD
     make_entry_single<12, 4, kLazy | (kOptStreamCh1 << 1), 8>(161),
-    make_entry_single<12, 4, kLazy | ((kOptStreamCh1 | kOptPrio) << 1), 8>(165),
 #endif
 };
 }  // namespace AGX_TU

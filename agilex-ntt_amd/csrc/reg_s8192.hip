@@ -11,10 +11,6 @@ const rb_entry kEntries[] = {
     make_entry_single<13, 5, kLazy, 4>(156),
     make_entry_single<13, 5, kFast, 4>(157),
     make_entry_single<13, 5, kExact, 4>(158),
-#ifdef AGX_DIAG
-    // A/B: R = 4 (16 coefficients per thread) streamed with one table entry per chunk: 60-64 VGPRs, no scratch -> 8 waves/SIMD
-    make_entry_single<13, 4, kLazy | (kOptStreamCh1 << 1), 8>(162),
-#endif
 };
 }  // namespace AGX_TU
 

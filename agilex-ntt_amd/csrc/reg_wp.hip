@@ -2,6 +2,7 @@
 // registry (rb_registry.hpp): ids are stable handles for tests and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices.
 #define AGX_TU tu_wp
 #include "rb_kernels.hpp"
+#include "rb_stream_opts.hpp"
 #include "wp_kernels.hpp"
 
 namespace agx {
@@ -21,6 +22,21 @@ const rb_entry kEntries[] = {
     make_entry_wp<8, 4, 4, kWpLazy, 5>(209), make_entry_wp<8, 4, 4, kWpFast, 5>(210), make_entry_wp<8, 4, 4, kWpExact, 5>(211),
     // n = 512: 16 x 32
     make_entry_wp<9, 4, 4, kWpLazy, 5>(212), make_entry_wp<9, 4, 4, kWpFast, 5>(213), make_entry_wp<9, 4, 4, kWpExact, 5>(214),
+#ifdef AGX_DIAG
+    // A/B shapes (lib/libagxntt_diag.so): other coefficients-per-lane splits and workgroup sizes
+    make_entry_wp<5, 5, 4, kWpLazy | (kOptSplitWord << 1), 4>(215),      // n = 32: ONE LANE per frame, every twiddle a scalar, split-word image
+    make_entry_wp<6, 4, 4, kWpLazy, 5>(216),                             // n = 64: 16 x 4
+    make_entry_wp<7, 3, 4, kWpLazy, 8>(217),                             // n = 128: 8 x 16 (three passes)
+    make_entry_wp<8, 3, 4, kWpLazy, 8>(218),                             // n = 256: 8 x 32 (three passes)
+    make_entry_wp<8, 5, 4, kWpLazy | (kOptSplitWord << 1), 4>(219),      // n = 256: 32 x 8
+    make_entry_wp<9, 5, 4, kWpLazy | (kOptSplitWord << 1), 4>(220),      // n = 512: 32 x 16 (two passes)
+    make_entry_single_mul2<9, 3, kLazy, 8, 5>(221),                      // n = 512: one wave per frame, 8 x 64 (the large sizes' kernel shape)
+    make_entry_wp<8, 4, 1, kWpLazy, 5>(222),                             // n = 256: one wave per workgroup
+    make_entry_wp<8, 4, 2, kWpLazy, 5>(223),
+    make_entry_wp<5, 3, 1, kWpLazy, 8>(224),                             // n = 32: one wave per workgroup
+    make_entry_wp<9, 4, 1, kWpLazy, 5>(225),                             // n = 512: one wave per workgroup
+    make_entry_wp<8, 4, 4, kWpLazy, 4>(226),                             // n = 256 at 4 waves/SIMD (128 VGPRs)
+#endif
 };
 }  // namespace AGX_TU
 

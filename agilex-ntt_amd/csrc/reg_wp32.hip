@@ -22,6 +22,14 @@ const rb_entry kEntries[] = {
     make_entry_wp32<7, 4, 4, 1, 8>(242),
     make_entry_wp32<8, 4, 4, 1, 8>(243),
     make_entry_wp32<9, 5, 4, 1, 4>(244),
+#ifdef AGX_DIAG
+    // A/B shapes
+    make_entry_wp32<5, 3, 4, 2, 8>(235),      // n = 32: 8 x 4
+    make_entry_wp32<9, 4, 4, 2, 8>(236),      // n = 512: 16 x 32 (three passes)
+    make_entry_wp32<7, 5, 4, 2, 4>(237),      // n = 128: 32 x 4
+    make_entry_wp32<8, 5, 4, 2, 4>(238),      // n = 256: 32 x 8
+    make_entry_wp32<6, 4, 4, 2, 8>(239),      // n = 64: 16 x 4
+#endif
 };
 }  // namespace AGX_TU
 

@@ -172,8 +172,6 @@ __device__ __forceinline__ void wp_store(const uint64_t (&v)[1 << R], uint64_t* 
     unsigned char* wimg = agx_dyn_lds + (size_t)wave * (FPW * F::image_bytes);                     \
     F f;                                                                                           \
     f.tid = lane % T;                                                                              \
-    f.blk = 0;                                                                                     \
-    f.split_log = 0;                                                                               \
     f.slab = reinterpret_cast<uint64_t*>(wimg + (size_t)(lane / T) * F::image_bytes);              \
     const prime_consts pc = consts[prime];                                                         \
     f.init_consts(pc.q, pc.est)
@@ -320,12 +318,9 @@ hipError_t init_wp_t() {
 // only shares an LDS allocation), MINW waves per SIMD
 template <int L, int R, int WPB, int ARITH, int MINW>
 constexpr rb_entry make_entry_wp(int id) {
-    rb_entry e{id, L, R, wp_geom<L, R>::FPW * WPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs, wp_lds_bytes<L, R, ARITH>(WPB),
-               &build_table_t<L, R, true>, &launch_wp_t<L, R, WPB, ARITH, MINW>, &init_wp_t<L, R, WPB, ARITH, MINW>,
-               (ARITH & 1) ? ((((ARITH >> 1) & kOptLazy16) != 0) ? 2 : 1) : 0,
-               &launch_inv_wp_t<L, R, WPB, ARITH, MINW>, &launch_mul_wp_t<L, R, WPB, ARITH, MINW>, 0, nullptr, false};
-    e.mul_parked = true;       // the fused product is legal at every one of these sizes
-    e.whole_only = true;
+    rb_entry e{id, L, R, wp_geom<L, R>::FPW * WPB, MINW, (uint32_t)rb_geom<L, R>::table_pairs, wp_lds_bytes<L, R, ARITH>(WPB),
+               &build_table_t<L, R>, &launch_wp_t<L, R, WPB, ARITH, MINW>, &init_wp_t<L, R, WPB, ARITH, MINW>, rb2_arith_level<ARITH>(),
+               &launch_inv_wp_t<L, R, WPB, ARITH, MINW>, &launch_mul_wp_t<L, R, WPB, ARITH, MINW>};
     return e;
 }
 
@@ -488,12 +483,10 @@ hipError_t init_wp32_t() {
 }
 template <int L, int R, int WPB, int TIER, int MINW>
 constexpr rb_entry make_entry_wp32(int id) {
-    rb_entry e{id, L, R, wp_geom<L, R>::FPW * WPB, true, MINW, (uint32_t)rb_geom<L, R>::table_pairs / 2, wp32_lds_bytes<L, R>(WPB),
+    rb_entry e{id, L, R, wp_geom<L, R>::FPW * WPB, MINW, (uint32_t)rb_geom<L, R>::table_pairs / 2, wp32_lds_bytes<L, R>(WPB),
                &build_table32_t<L, R>, &launch_wp32_t<L, R, WPB, TIER, MINW>, &init_wp32_t<L, R, WPB, TIER, MINW>, 1,
-               &launch_inv_wp32_t<L, R, WPB, TIER, MINW>, &launch_mul_wp32_t<L, R, WPB, TIER, MINW>, 0, nullptr, false};
-    e.mul_parked = true;
+               &launch_inv_wp32_t<L, R, WPB, TIER, MINW>, &launch_mul_wp32_t<L, R, WPB, TIER, MINW>};
     e.narrow = TIER;
-    e.whole_only = true;
     return e;
 }
 #endif  // AGX_WP_Q32

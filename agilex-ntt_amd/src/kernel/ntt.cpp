@@ -27,10 +27,27 @@ int transform(uint64_t* coeffs, uint32_t n, uint64_t q, uint32_t frames, uint64_
     return e == hipSuccess ? AGX_OK : (e == hipErrorOutOfMemory ? AGX_ERR_ALLOC : AGX_ERR_HIP);
 }
 
+// the same over several devices: a group for the duration of the call, the frames dealt in contiguous blocks (in place: a shard's
+// pipeline has staged a chunk before it writes that chunk's results back)
+int transform_on(uint64_t* coeffs, uint32_t n, uint64_t q, uint32_t frames, uint64_t psi, bool inverse, const std::vector<int>& devices) {
+    if (!coeffs) return AGX_ERR_NULL_POINTER;
+    if (frames == 0) return AGX_OK;
+    agx_ntt_group* group = nullptr;
+    int rc = agx_ntt_group_create_auto(&group, devices.data(), (uint32_t)devices.size(), n, 1, &q, psi ? &psi : nullptr);
+    if (rc != AGX_OK) return rc;
+    rc = inverse ? agx_ntt_group_inverse_host(group, coeffs, coeffs, frames) : agx_ntt_group_forward_host(group, coeffs, coeffs, coeffs, frames);
+    agx_ntt_group_destroy(group);
+    return rc;
+}
+
 }  // namespace
 
-int ntt(uint64_t* coeffs, uint32_t n, uint64_t q, uint32_t frames, uint64_t psi) { return transform(coeffs, n, q, frames, psi, false); }
-int intt(uint64_t* coeffs, uint32_t n, uint64_t q, uint32_t frames, uint64_t psi) { return transform(coeffs, n, q, frames, psi, true); }
+int ntt(uint64_t* coeffs, uint32_t n, uint64_t q, uint32_t frames, uint64_t psi, const std::vector<int>& devices) {
+    return devices.empty() ? transform(coeffs, n, q, frames, psi, false) : transform_on(coeffs, n, q, frames, psi, false, devices);
+}
+int intt(uint64_t* coeffs, uint32_t n, uint64_t q, uint32_t frames, uint64_t psi, const std::vector<int>& devices) {
+    return devices.empty() ? transform(coeffs, n, q, frames, psi, true) : transform_on(coeffs, n, q, frames, psi, true, devices);
+}
 
 void ntt_input_kernel(const buffer<uint64_t>& inData, const buffer<uint64_t>& inData2, const buffer<uint64_t>& modulus,
                       const buffer<uint64_t>& twiddleFactors, const buffer<uint64_t>& barrettTwiddleFactors,

@@ -172,7 +172,11 @@ def _timed(torch, fn, launches, warmup):
     return e0.elapsed_time(e1) / launches
 
 
-PROFILE_TAG = "r03f"      # the committed per-operation counter summaries the secondary lines point at
+PROFILE_TAG = "r04"       # the committed per-operation counter summaries the secondary lines point at
+
+
+def per_slab_elems(slabs):
+    return slabs[0].numel()
 
 
 def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None, idle_w=None):
@@ -227,6 +231,22 @@ def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None, id
             ms = _timed(torch, lambda i: pn.polymul(views[i % ns].data_ptr(), views[(i + 1) % ns].data_ptr(), views[i % ns].data_ptr(), 0, batch, stream), 200, 4)
             entry("polymul_n4096_30bit", f"n={nn}, {NUM_PRIMES} primes of 30 bits, batch {batch}, fused product in one launch, 32-bit arithmetic", units, 24 * nn, ms, "products/s", 200, profile="mul4096q30")
         pn.close()
+    # the small sizes (n = 32 is the smallest size of the reference's own table, include/kernel/ntt.h:11-12): wave-packed kernels
+    # (csrc/wp_kernels.hpp), >= 1 GiB per launch, the same four slabs rotated; 60-bit primes, and 30-bit ones on the 32-bit kernels
+    for nn, bits, tag in ((32, 60, "fwd32"), (256, 60, "fwd256"), (512, 60, "fwd512"), (32, 30, "fwd32q30"), (512, 30, "fwd512q30")):
+        bsm = per_slab_elems(slabs) // (NUM_PRIMES * nn)
+        pn = agx.Plan(nn, agx.find_primes(bits, nn, NUM_PRIMES))
+        for k, v in enumerate(slabs):
+            pn.fill_synthetic(v.data_ptr(), bsm, k * bsm, 42, stream)
+        ms = _timed(torch, lambda i: pn.forward(slabs[i % ns].data_ptr(), slabs[i % ns].data_ptr(), bsm, stream), 200, 8)
+        entry(f"forward_n{nn}" + ("" if bits == 60 else f"_{bits}bit"), f"n={nn}, {NUM_PRIMES} primes of {bits} bits, batch {bsm}, forward NTT in place, "
+              f"{'32-bit' if bits < 32 else '64-bit'} wave-packed kernels (several frames per wave, no workgroup barrier)", NUM_PRIMES * bsm, 16 * nn, ms, "NTT/s", 200, profile=tag)
+        if (nn, bits) in ((32, 60), (512, 60)):
+            ms = _timed(torch, lambda i: pn.inverse(slabs[i % ns].data_ptr(), slabs[i % ns].data_ptr(), bsm, stream), 200, 8)
+            entry(f"inverse_n{nn}", f"n={nn}, {NUM_PRIMES} primes of {bits} bits, batch {bsm}, inverse NTT in place", NUM_PRIMES * bsm, 16 * nn, ms, "NTT/s", 200, profile=tag.replace("fwd", "inv"))
+            ms = _timed(torch, lambda i: pn.polymul(slabs[i % ns].data_ptr(), slabs[(i + 1) % ns].data_ptr(), slabs[i % ns].data_ptr(), 0, bsm, stream), 100, 4)
+            entry(f"polymul_n{nn}", f"n={nn}, {NUM_PRIMES} primes of {bits} bits, batch {bsm}, fused product in one launch (both transforms in registers)", NUM_PRIMES * bsm, 24 * nn, ms, "products/s", 100, profile=tag.replace("fwd", "mul"))
+        pn.close()
     for s in slabs:
         s.untyped_storage().resize_(0)      # give the 2 GiB back before the large slices
     torch.cuda.empty_cache()
@@ -267,6 +287,136 @@ def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None, id
     return out
 
 
+def bound_note(power, value_per_gpu):
+    """how far the headline kernel is from its own power bound, from this run's samples: at the board's cap throughput is
+    (cap - idle) / (energy per NTT); VERDICT r03: the 64-bit butterfly sits at that bound, not at an instruction-scheduling one"""
+    if not power or power.get("energy_uj_per_ntt") is None or power.get("power_cap_w") is None or power.get("idle_w") is None:
+        return None
+    e, cap, idle = power["energy_uj_per_ntt"], power["power_cap_w"], power["idle_w"]
+    at_cap = (cap - idle) / (e * 1e-6)
+    return {"bound": "board power cap", "energy_uj_per_ntt": e, "power_cap_w": cap, "idle_w": idle, "measured_socket_w_median": power.get("socket_power_w_median"),
+            "value_at_cap": at_cap, "value_over_value_at_cap": value_per_gpu / at_cap,
+            "roofline_target_value": 0.60 * HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_NTT, "socket_w_the_target_would_draw": idle + 0.60 * HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_NTT * e * 1e-6,
+            "note": "value_at_cap = (power_cap_w - idle_w) / energy_uj_per_ntt: NTT/s per GPU this kernel reaches when the board draws its cap; "
+                    "value_over_value_at_cap ~ 1 means the kernel is power-bound (DESIGN.md 3.5)"}
+
+
+def main_group(args, torch, agx):
+    """--single-process: the same step on N devices through agx_ntt_group_* (include/agx_ntt.h section 5).  One process, no
+    torch.distributed: the group's host threads launch every shard on its own stream; the timed region is bracketed by
+    agx_ntt_group_synchronize (the barrier) and per-device HIP events on the shards' streams give per_rank."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    world = len(devices)
+    batch = args.batch
+    qs = agx.find_primes(PRIME_BITS, N_COEFF, NUM_PRIMES)
+    grp = agx.DeviceGroup(devices, N_COEFF, qs)
+    per_slab = NUM_PRIMES * batch * N_COEFF
+    L = agx.lib()
+    slabs, ext = [], []
+    for i, d in enumerate(devices):
+        torch.cuda.set_device(d)
+        _, plan_h, stream_h = grp.shard(i)
+        ext.append(torch.cuda.ExternalStream(stream_h, device=torch.device("cuda", d)))
+        mine = [torch.empty(per_slab, dtype=torch.int64, device=f"cuda:{d}") for _ in range(NUM_SLABS)]
+        for k, sl in enumerate(mine):
+            rc = L.agx_ntt_fill_synthetic(plan_h, sl.data_ptr(), batch, (k * world + i) * batch, 42, stream_h)
+            if rc:
+                raise SystemExit(f"fill_synthetic failed on shard {i}: {rc}")
+        slabs.append(mine)
+    grp.synchronize()
+    # correctness guard before timing: INTT(NTT(x)) == x on slab 0 of every shard, through the group calls
+    checks = []
+    for i, d in enumerate(devices):
+        torch.cuda.set_device(d)
+        checks.append(slabs[i][0].clone())
+    torch.cuda.synchronize()
+    grp.forward([c.data_ptr() for c in checks], [c.data_ptr() for c in checks], [batch] * world)
+    grp.inverse([c.data_ptr() for c in checks], [c.data_ptr() for c in checks], [batch] * world)
+    grp.synchronize()
+    for i in range(world):
+        if not torch.equal(checks[i], slabs[i][0]):
+            raise SystemExit(f"round trip failed on shard {i}: refusing to report a number")
+    del checks
+    batches = [batch] * world
+
+    def step(it):
+        ptrs = [slabs[i][it % NUM_SLABS].data_ptr() for i in range(world)]
+        grp.forward(ptrs, ptrs, batches)
+
+    sampler = PowerSampler(torch, devices[0])
+    t_idle0 = time.perf_counter()
+    time.sleep(0.4)
+    idle_w = sampler.median_w(t_idle0, time.perf_counter())
+    t_busy0 = time.perf_counter() + 0.2
+    ramp_steps = 0
+    t_end = time.perf_counter() + args.ramp_seconds
+    while time.perf_counter() < t_end:
+        for _ in range(64):
+            step(ramp_steps)
+            ramp_steps += 1
+        grp.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    grp.synchronize()      # the barrier: every shard idle
+    ev = []
+    for i, d in enumerate(devices):
+        torch.cuda.set_device(d)
+        ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+    t0 = time.perf_counter()
+    for i in range(world):
+        ev[i][0].record(ext[i])
+    for it in range(args.steps):
+        step(args.warmup + it)
+    for i in range(world):
+        ev[i][1].record(ext[i])
+    grp.synchronize()
+    elapsed = time.perf_counter() - t0      # all shards: the slowest one defines it
+    t_busy1 = time.perf_counter()
+    power = sampler.window(t_busy0, t_busy1)
+    kernel_ms = [ev[i][0].elapsed_time(ev[i][1]) / args.steps for i in range(world)]
+    per_rank = [{"rank": i, "device": devices[i], "elapsed_s": kernel_ms[i] * args.steps * 1e-3, "kernel_ms": kernel_ms[i],
+                 "socket_power_w_median": power["socket_power_w_median"] if (power and devices[i] == devices[0]) else None,
+                 "sclk_mhz_median": power["sclk_mhz_median"] if (power and devices[i] == devices[0]) else None} for i in range(world)]
+    ntts = NUM_PRIMES * batch
+    value = agx.aggregate_throughput(ntts, args.steps, world, elapsed)
+    achieved = value / world * ALGO_BYTES_PER_NTT / 1e9
+    slow_ms = max(kernel_ms)
+    achieved_events = ntts * ALGO_BYTES_PER_NTT / (slow_ms * 1e-3) / 1e9
+    if power and idle_w is not None and power["socket_power_w_median"] is not None and len(set(devices)) == world:
+        power["idle_w"] = idle_w
+        power["energy_uj_per_ntt"] = (power["socket_power_w_median"] - idle_w) / (value / world) * 1e6
+    out = {
+        "metric": "batched n=4096 forward NTTs/sec at 1/2/4/8 MI355X; %HBM roofline",
+        "value": value, "unit": "NTT/s", "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": f"n={N_COEFF}, {NUM_PRIMES}-prime RNS ({PRIME_BITS}-bit), batch={batch} polynomials per shard, "
+                        "forward negacyclic NTT in place (BASELINE.json configs[2])",
+            "n": N_COEFF, "primes": NUM_PRIMES, "batch_per_gpu": batch, "ntts_per_step_per_gpu": ntts, "slabs_rotated": NUM_SLABS,
+            "clock_ramp_steps_before_warmup": ramp_steps, "parallelism": f"batch-sharded x{world}, no collective",
+            "launch": "single process: agx_ntt_group_* (one shard, host thread and stream per device; no torch.distributed)", "devices": devices,
+            "polys_per_sec": value / NUM_PRIMES,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel_ms": slow_ms, "achieved_from_kernel_events": achieved_events,
+            "frac_from_kernel_events": achieved_events / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ntts * ALGO_BYTES_PER_NTT,
+        },
+        "per_rank": per_rank,
+    }
+    note = bound_note(power, value / world)
+    if note:
+        out["roofline"]["bound_note"] = note
+    if power:
+        out["power"] = power
+    sampler.stop()
+    print(json.dumps(out), flush=True)
+    grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,6 +425,10 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="polynomials per GPU per step")
     ap.add_argument("--ramp-seconds", type=float, default=RAMP_SECONDS,
                     help="set-up: run the step this long before the W warm-up steps so the GPU clock has ramped (0 = cold start)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive the N GPUs from ONE process through the library's own multi-GPU driver (agx_ntt_group_*: one shard, host thread and "
+                         "stream per device, no torch.distributed); same JSON line, per_rank from per-device HIP events")
+    ap.add_argument("--devices", type=str, default=None, help="with --single-process: explicit device list, e.g. 0,0 (two shards on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (inverse, poly-mul, n=16384, n=32768)")
     args = ap.parse_args()
@@ -283,6 +437,8 @@ def main():
 
     import agilex_ntt_amd as agx
 
+    if args.single_process:
+        return main_group(args, torch, agx)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch N>1 through torch.distributed.run")
@@ -407,6 +563,9 @@ def main():
         },
         "per_rank": per_rank,
     }
+    note = bound_note(power, value / world)
+    if note:
+        out["roofline"]["bound_note"] = note      # the three numbers the "power-bound" argument rests on, measured in this run
     if power and rank == 0:
         out["power"] = power
     if world == 1 and not args.no_secondary:

@@ -1,4 +1,4 @@
-"""The diagnostics / A-B kernels (trace twin 70, streaming kernels 83 / 84) are not in the product library; they are
+"""The diagnostics / A-B kernels (trace twin 70, the A/B twins 147 / 161 / 115 / 160 / 114) are not in the product library; they are
 built into lib/libagxntt_diag.so by `make diag`.  A process binds ONE library, so these checks run in a child
 process with AGX_NTT_LIB pointing at the diag build (tests/diag_child.py)."""
 import ctypes
@@ -43,3 +43,12 @@ def test_ab_registry_entries_under_the_diag_library(agx):
     tail = r.stdout[-3000:] + r.stderr[-2000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+    # the child's own count, into this test's captured output (-s / -rP / the junit log show it) and into a file beside the other records
+    summary = r.stdout.splitlines()[-1]
+    print(f"child pytest under lib/libagxntt_diag.so: {summary}")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "diag_child_pytest_summary.txt"), "w") as f:
+            f.write(summary + "\n")
+    except OSError:
+        pass

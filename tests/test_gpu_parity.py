@@ -184,17 +184,16 @@ def test_structured_known_answers(agx, dev, n):
 
 
 @pytest.mark.parametrize("bits", [30, 60, 61, 62])
-@pytest.mark.parametrize("config", ["default", 2, 12, 13, 27, 28, 39, 50, 66, 86, 89, 90, 91, 92, 93])
+@pytest.mark.parametrize("config", ["default", 91, 92, 93, 159, 147, 161, 70])
 def test_n4096_kernel_registry_variants(agx, orc, dev, bits, config):
-    """every registered n=4096 kernel (first-generation exact; second-generation exact, fast and
-    16q-lazy; the priority-raising defaults 90/91/92) against the oracle, for 30-, 60-, 61- and 62-bit moduli (the diagnostics kernels 70/83/84
-    live in lib/libagxntt_diag.so: tests/test_gpu_diag.py); a form whose lazy range does
-    not fit the modulus must be refused, and the default must fall back to a legal one"""
+    """every registered n=4096 kernel (exact 91, fast 92, 16q-lazy 93 and its forward companion 159; the A/B twins 147 / 161 and the
+    trace twin 70 of lib/libagxntt_diag.so: tests/test_gpu_diag.py) against the oracle, for 30-, 60-, 61- and 62-bit moduli; a form
+    whose lazy range does not fit the modulus must be refused, and the default must fall back to a legal one"""
     n, batch, primes = 4096, 3, 2
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, bits, primes, inverse=False)
     if config != "default":
         # fast forms need q <= 2^61, the 16q-lazy form q <= 2^60: anything else must be refused
-        illegal = (config in (12, 27, 92) and bits == 62) or (config in (39, 50, 66, 86, 89, 90, 93) and bits >= 61)
+        illegal = (config == 92 and bits == 62) or (config in (93, 159, 147, 161, 70) and bits >= 61)
         if illegal:
             if config not in PRODUCT_IDS and not agx.LIB_PATH.endswith("libagxntt_diag.so"):
                 plan.close()
@@ -716,7 +715,7 @@ def test_polymul_every_fused_kernel(agx, orc, dev, n, bits):
     plan.close()
 
 
-@pytest.mark.parametrize("n,config", [(16384, None), (32768, None), (16384, 37), (16384, 120), (32768, 123)])
+@pytest.mark.parametrize("n,config", [(16384, None), (32768, None), (16384, 160), (16384, 120), (32768, 123)])
 def test_one_launch_product_with_aliasing_and_no_scratch(agx, orc, dev, n, config):
     """the parked-operand fused product (polymul_rb2_park) at n = 16384 / 32768 -- the R = 5 defaults park NTT(first) thread-privately
     in c's own frame, registry id 37 (R = 4, A/B) parks it in natural order and redistributes through LDS; 120 / 123: the fast /
@@ -763,20 +762,11 @@ def test_polymul_lazy_operands(agx, orc, dev):
 # every entry of the kernel registry with the size it serves and the largest modulus its arithmetic admits
 # (exact: 62 bits, fast: 61, 16q-lazy: 60); defaults are reached by the other tests, this one reaches the rest
 REGISTRY = [
-    (2, 4096, 62), (12, 4096, 61), (13, 4096, 62), (27, 4096, 61), (28, 4096, 62), (39, 4096, 60), (50, 4096, 60),
-    (66, 4096, 60), (90, 4096, 60), (91, 4096, 62), (92, 4096, 61), (93, 4096, 60), (86, 4096, 60), (89, 4096, 60), (87, 4096, 60), (97, 4096, 60), (98, 4096, 60),
-    (101, 4096, 60), (102, 4096, 60), (103, 4096, 60), (104, 4096, 60), (105, 4096, 60), (106, 4096, 60), (107, 4096, 60),
-    (29, 1024, 61), (30, 1024, 62), (40, 1024, 60), (61, 1024, 60), (62, 1024, 60), (63, 1024, 60),
-    (31, 2048, 61), (32, 2048, 62), (41, 2048, 60), (59, 2048, 60), (94, 4096, 60), (95, 4096, 60), (96, 4096, 60),
-    (33, 8192, 61), (34, 8192, 62), (42, 8192, 60), (64, 8192, 60), (65, 8192, 60),
-    (35, 16384, 61), (36, 16384, 62), (43, 16384, 60), (57, 16384, 60), (58, 16384, 60), (37, 16384, 60),
-    (44, 16384, 62), (45, 16384, 61), (46, 16384, 60), (47, 32768, 62), (48, 32768, 61), (49, 32768, 60),
-    (51, 16384, 62), (52, 16384, 61), (53, 16384, 60), (54, 32768, 60), (55, 32768, 61), (56, 32768, 62),
-    # whole-frame R = 5 kernels (117 / 119 defaults, 120-123 fast / exact forms, 114-116 / 118 A/B)
-    (117, 16384, 60), (119, 32768, 60), (120, 16384, 61), (121, 32768, 61), (122, 16384, 62), (123, 32768, 62),
-    (114, 32768, 60), (115, 16384, 60), (116, 32768, 60), (118, 16384, 60), (124, 16384, 60), (125, 32768, 60), (145, 16384, 60), (146, 32768, 60), (160, 16384, 60), (161, 4096, 60), (165, 4096, 60), (162, 8192, 60), (164, 16384, 60), (127, 4096, 60), (147, 4096, 60), (148, 4096, 60), (159, 4096, 60), (129, 1024, 60), (149, 1024, 60),
-    # streamed single-frame kernels of n = 1024 / 2048 / 8192 (lazy, fast, exact)
+    (91, 4096, 62), (92, 4096, 61), (93, 4096, 60), (159, 4096, 60), (147, 4096, 60), (161, 4096, 60), (70, 4096, 60),
+    # streamed single-frame kernels (lazy, fast, exact): n = 1024 / 2048 / 8192, 16384 (117 + forward companion 164), 32768; A/B twins 115 / 160 / 114
     (150, 1024, 60), (151, 1024, 61), (152, 1024, 62), (153, 2048, 60), (154, 2048, 61), (155, 2048, 62), (156, 8192, 60), (157, 8192, 61), (158, 8192, 62),
+    (117, 16384, 60), (164, 16384, 60), (120, 16384, 61), (122, 16384, 62), (115, 16384, 60), (160, 16384, 60),
+    (119, 32768, 60), (121, 32768, 61), (123, 32768, 62), (114, 32768, 60),
     # 32-bit arithmetic: tier 2 (every q < 2^30), tier 1 (every q < 2^31)
     (130, 1024, 30), (131, 2048, 30), (132, 4096, 30), (133, 8192, 30), (134, 16384, 30), (135, 32768, 30),
     (136, 1024, 31), (137, 2048, 31), (138, 4096, 31), (139, 8192, 31), (140, 16384, 31), (141, 32768, 31),
@@ -784,6 +774,9 @@ REGISTRY = [
     (200, 32, 60), (201, 32, 61), (202, 32, 62), (203, 64, 60), (204, 64, 61), (205, 64, 62), (206, 128, 60), (207, 128, 61), (208, 128, 62),
     (209, 256, 60), (210, 256, 61), (211, 256, 62), (212, 512, 60), (213, 512, 61), (214, 512, 62),
     (230, 32, 30), (231, 64, 30), (232, 128, 30), (233, 256, 30), (234, 512, 30), (240, 32, 31), (241, 64, 31), (242, 128, 31), (243, 256, 31), (244, 512, 31),
+    # A/B shapes of the wave-packed kernels (lib/libagxntt_diag.so)
+    (215, 32, 60), (216, 64, 60), (217, 128, 60), (218, 256, 60), (219, 256, 60), (220, 512, 60), (221, 512, 60), (222, 256, 60), (223, 256, 60), (224, 32, 60), (225, 512, 60), (226, 256, 60),
+    (235, 32, 30), (236, 512, 30), (237, 128, 30), (238, 256, 30), (239, 64, 30),
 ]
 
 
@@ -942,12 +935,11 @@ def test_polymul_squaring_with_and_without_aliasing(agx, orc, dev, n, bits):
     plan.close()
 
 
-@pytest.mark.parametrize("config,n,batch", [(117, 16384, 333), (119, 32768, 290), (118, 16384, 333), (116, 32768, 290), (43, 16384, 333), (57, 16384, 333), (37, 16384, 333)])
+@pytest.mark.parametrize("config,n,batch", [(117, 16384, 333), (119, 32768, 290)])
 def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config, n, batch):
     """the loop kernels (a resident grid walking over the frames -- 117 / 119: the n = 16384 / 32768 defaults, inverse by the
-    ticket-drawing loop kernel; 118 / 116: forward too; 43 / 37 / 57: the R = 4 generation, ticket-drawing and fixed-stride) on more
-    frames than the chip holds workgroups, a frame count that is not a multiple of the grid, two primes, in place: forward and
-    inverse against the oracle"""
+    ticket-drawing loop kernel) on more frames than the chip holds workgroups, a frame count that is not a multiple of the grid,
+    two primes, in place: forward and inverse against the oracle"""
     primes = 2
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, primes)
     _select(agx, plan, config)
@@ -965,13 +957,13 @@ def test_loop_kernels_more_frames_than_workgroups(agx, orc, dev, config, n, batc
     plan.close()
 
 
-@pytest.mark.parametrize("config", [117, 118, 37])
+@pytest.mark.parametrize("config", [117, 119])
 def test_dynamic_loop_kernels_on_two_streams_of_one_plan(agx, orc, dev, config):
-    """the ticket-drawing loop kernels (117: the default's inverse; 118 / 37: forward too) launched back to back on two streams of ONE
+    """the ticket-drawing loop kernels (the inverse of the n = 16384 / 32768 defaults) launched back to back on two streams of ONE
     plan, so that launches overlap: the plan keeps one ticket pair per stream, so both results must be right, repeatedly"""
     import torch
 
-    n, batch = 16384, 700
+    n, batch = (16384, 700) if config == 117 else (32768, 400)
     plan, tabs = _plan_from_oracle_tables(agx, orc, n, 60, 1)
     _select(agx, plan, config)
     q, psi, tw, pre = tabs[0]
@@ -993,7 +985,7 @@ def test_dynamic_loop_kernels_on_two_streams_of_one_plan(agx, orc, dev, config):
     plan.close()
 
 
-@pytest.mark.parametrize("n,config,batch", [(32768, None, 1100), (16384, None, 2100), (32768, 54, 1100), (16384, 53, 2100)])
+@pytest.mark.parametrize("n,config,batch", [(32768, None, 1100), (16384, None, 2100), (32768, 114, 1100), (16384, 115, 2100)])
 def test_large_frames_on_many_rounds_of_workgroups(agx, orc, dev, n, config, batch):
     """n = 32768 / 16384 on several rounds of workgroups per CU: the whole-frame R = 5 defaults and the two-halves-in-turn kernels
     they replaced (registry ids 54 / 53, A/B): forward in place and inverse against the oracle"""

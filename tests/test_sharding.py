@@ -88,3 +88,49 @@ def test_world_size_2_gloo(tmp_path, orc):
         whole = orc.forward(orc.fill_splitmix(total * n, 100 + p, q), q, tw, pre, n)
         got = np.concatenate([r0[p * 5 * n:(p + 1) * 5 * n], r1[p * 6 * n:(p + 1) * 6 * n]])
         assert np.array_equal(got, whole)
+
+
+# ---- the library-level group (include/agx_ntt.h section 5): block arithmetic and argument checks need no device ----------------
+def test_group_block_arithmetic_matches_the_reference_minibatches(agx):
+    """agx_ntt_shard_range deals F frames to C shards in the reference's minibatch sizes -- floor(F / C) + [i < F mod C]
+    (src/kernel/ntt.cpp:526-536) -- as contiguous blocks that tile [0, F): ragged counts, more shards than frames, zero frames"""
+    for frames, shards in [(0, 1), (0, 5), (1, 1), (1, 8), (3, 8), (7, 8), (8, 8), (9, 8), (11, 2), (4096, 8), (4097, 8), (65536, 3), (2**40 + 5, 7)]:
+        nxt = 0
+        for i in range(shards):
+            first, count = agx.shard_block(frames, shards, i)
+            assert first == nxt
+            assert count == frames // shards + (1 if i < frames % shards else 0)
+            nxt = first + count
+        assert nxt == frames
+    import pytest
+
+    for bad in [(10, 0, 0), (10, 2, 2), (10, 2, 7)]:
+        with pytest.raises(agx.AgxError) as ei:
+            agx.shard_block(*bad)
+        assert ei.value.status == 5
+    assert agx.lib().agx_ntt_shard_range(10, 2, 0, None, None) == 1
+
+
+def test_group_calls_fail_loudly_without_a_device(agx):
+    """no GPU here: creating a group must say AGX_ERR_NO_DEVICE (6), never fall back; argument checks come first"""
+    import ctypes
+
+    import pytest
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    L = agx.lib()
+    h = ctypes.c_void_p(None)
+    devs = (ctypes.c_int * 2)(0, 0)
+    q = np.array([agx.find_primes(60, 4096)[0]], dtype=np.uint64)
+    p64 = ctypes.POINTER(ctypes.c_uint64)
+    qp = q.ctypes.data_as(p64)
+    assert L.agx_ntt_group_create_auto(ctypes.byref(h), devs, 2, 4096, 1, qp, None) == 6 and not h.value
+    assert L.agx_ntt_group_create_auto(ctypes.byref(h), devs, 0, 4096, 1, qp, None) == 5      # no shards
+    assert L.agx_ntt_group_create_auto(ctypes.byref(h), devs, 2, 4095, 1, qp, None) == 2      # bad size
+    assert L.agx_ntt_group_create_auto(None, devs, 2, 4096, 1, qp, None) == 1
+    assert L.agx_ntt_group_create_auto(ctypes.byref(h), None, 2, 4096, 1, qp, None) == 1
+    assert L.agx_ntt_group_forward_host(None, qp, qp, qp, 1) == 1
+    assert L.agx_ntt_group_synchronize(None) == 1
+    assert L.agx_ntt_group_destroy(None) == 0
