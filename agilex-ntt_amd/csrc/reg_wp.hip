@@ -11,31 +11,26 @@ namespace AGX_TU {
 constexpr int kWpLazy = 1 | ((kOptPad | kOptSelect | kOptLazy16 | kOptLazyInv | kOptNtLoad | kOptNtStore | kOptEstReduce | kOptStreamTw | kOptPinBf) << 1);   // q <= 2^60
 constexpr int kWpFast = 1 | ((kOptPad | kOptSelect | kOptNtLoad | kOptNtStore | kOptStreamTw | kOptPinBf) << 1);                                            // q <= 2^61
 constexpr int kWpExact = 0 | ((kOptPad | kOptNtLoad | kOptNtStore | kOptStreamTw | kOptPinBf) << 1);                                                        // q < 2^62, reference op sequence
+// One wave per workgroup everywhere: nothing is shared between the waves of a group but the LDS allocation, and a wave that retires alone frees
+// its slot at once (four waves per workgroup: -1 ... -5 %, profiles/r04_small_sizes_sweeps.txt).
 const rb_entry kEntries[] = {
     // n = 32: 8 coefficients per lane, 4 lanes per frame, 16 frames per wave
-    make_entry_wp<5, 3, 4, kWpLazy, 8>(200), make_entry_wp<5, 3, 4, kWpFast, 8>(201), make_entry_wp<5, 3, 4, kWpExact, 8>(202),
+    make_entry_wp<5, 3, 1, kWpLazy, 8>(200), make_entry_wp<5, 3, 1, kWpFast, 8>(201), make_entry_wp<5, 3, 1, kWpExact, 8>(202),
     // n = 64: 8 x 8
-    make_entry_wp<6, 3, 4, kWpLazy, 8>(203), make_entry_wp<6, 3, 4, kWpFast, 8>(204), make_entry_wp<6, 3, 4, kWpExact, 8>(205),
+    make_entry_wp<6, 3, 1, kWpLazy, 8>(203), make_entry_wp<6, 3, 1, kWpFast, 8>(204), make_entry_wp<6, 3, 1, kWpExact, 8>(205),
     // n = 128: 16 coefficients per lane, 8 lanes per frame
-    make_entry_wp<7, 4, 4, kWpLazy, 5>(206), make_entry_wp<7, 4, 4, kWpFast, 5>(207), make_entry_wp<7, 4, 4, kWpExact, 5>(208),
+    make_entry_wp<7, 4, 1, kWpLazy, 5>(206), make_entry_wp<7, 4, 1, kWpFast, 5>(207), make_entry_wp<7, 4, 1, kWpExact, 5>(208),
     // n = 256: 16 x 16
-    make_entry_wp<8, 4, 4, kWpLazy, 5>(209), make_entry_wp<8, 4, 4, kWpFast, 5>(210), make_entry_wp<8, 4, 4, kWpExact, 5>(211),
+    make_entry_wp<8, 4, 1, kWpLazy, 5>(209), make_entry_wp<8, 4, 1, kWpFast, 5>(210), make_entry_wp<8, 4, 1, kWpExact, 5>(211),
     // n = 512: 16 x 32
-    make_entry_wp<9, 4, 4, kWpLazy, 5>(212), make_entry_wp<9, 4, 4, kWpFast, 5>(213), make_entry_wp<9, 4, 4, kWpExact, 5>(214),
+    make_entry_wp<9, 4, 1, kWpLazy, 5>(212), make_entry_wp<9, 4, 1, kWpFast, 5>(213), make_entry_wp<9, 4, 1, kWpExact, 5>(214),
 #ifdef AGX_DIAG
-    // A/B shapes (lib/libagxntt_diag.so): other coefficients-per-lane splits and workgroup sizes
-    make_entry_wp<5, 5, 4, kWpLazy | (kOptSplitWord << 1), 4>(215),      // n = 32: ONE LANE per frame, every twiddle a scalar, split-word image
-    make_entry_wp<6, 4, 4, kWpLazy, 5>(216),                             // n = 64: 16 x 4
-    make_entry_wp<7, 3, 4, kWpLazy, 8>(217),                             // n = 128: 8 x 16 (three passes)
-    make_entry_wp<8, 3, 4, kWpLazy, 8>(218),                             // n = 256: 8 x 32 (three passes)
-    make_entry_wp<8, 5, 4, kWpLazy | (kOptSplitWord << 1), 4>(219),      // n = 256: 32 x 8
-    make_entry_wp<9, 5, 4, kWpLazy | (kOptSplitWord << 1), 4>(220),      // n = 512: 32 x 16 (two passes)
-    make_entry_single_mul2<9, 3, kLazy, 8, 5>(221),                      // n = 512: one wave per frame, 8 x 64 (the large sizes' kernel shape)
-    make_entry_wp<8, 4, 1, kWpLazy, 5>(222),                             // n = 256: one wave per workgroup
-    make_entry_wp<8, 4, 2, kWpLazy, 5>(223),
-    make_entry_wp<5, 3, 1, kWpLazy, 8>(224),                             // n = 32: one wave per workgroup
-    make_entry_wp<9, 4, 1, kWpLazy, 5>(225),                             // n = 512: one wave per workgroup
-    make_entry_wp<8, 4, 4, kWpLazy, 4>(226),                             // n = 256 at 4 waves/SIMD (128 VGPRs)
+    // A/B shapes kept in lib/libagxntt_diag.so (measured in profiles/r04_small_sizes_sweeps.txt; 216-219, 223, 225, 226 measured there and deleted)
+    make_entry_wp<5, 5, 4, kWpLazy | (kOptSplitWord << 1), 4>(215),      // n = 32: ONE LANE per frame, every twiddle a scalar, split-word image: -5 % forward
+    make_entry_wp<9, 5, 1, kWpLazy | (kOptSplitWord << 1), 4>(220),      // n = 512: 32 x 16 (two passes): +1 ... +2 % forward / inverse, -5 % product
+    make_entry_single_mul2<9, 3, kLazy, 8, 5>(221),                      // n = 512: one wave per frame, 8 x 64 (the large sizes' kernel shape): equal
+    make_entry_wp<8, 4, 4, kWpLazy, 5>(222),                             // n = 256: four waves per workgroup
+    make_entry_wp<5, 3, 4, kWpLazy, 8>(224),                             // n = 32: four waves per workgroup: -5 % forward, -7 % inverse and product
 #endif
 };
 }  // namespace AGX_TU

@@ -10,25 +10,22 @@
 namespace agx {
 namespace AGX_TU {
 const rb_entry kEntries[] = {
-    // tier 2 (every q < 2^30)
-    make_entry_wp32<5, 5, 4, 2, 4>(230),      // n = 32: ONE LANE per frame, the whole transform in 32 registers, every twiddle a scalar
-    make_entry_wp32<6, 3, 4, 2, 8>(231),      // n = 64: 8 x 8
-    make_entry_wp32<7, 4, 4, 2, 8>(232),      // n = 128: 16 x 8
-    make_entry_wp32<8, 4, 4, 2, 8>(233),      // n = 256: 16 x 16
-    make_entry_wp32<9, 5, 4, 2, 4>(234),      // n = 512: 32 x 16
+    // tier 2 (every q < 2^30); one wave per workgroup (reg_wp.hip)
+    make_entry_wp32<5, 3, 1, 2, 8>(230),      // n = 32: 8 x 4
+    make_entry_wp32<6, 3, 1, 2, 8>(231),      // n = 64: 8 x 8
+    make_entry_wp32<7, 4, 1, 2, 8>(232),      // n = 128: 16 x 8
+    make_entry_wp32<8, 4, 1, 2, 8>(233),      // n = 256: 16 x 16
+    make_entry_wp32<9, 4, 1, 2, 8>(234),      // n = 512: 16 x 32 (three passes; 32 x 16 spills in the product: 40 vs 55 % of its 24n bytes)
     // tier 1 (every q < 2^31)
-    make_entry_wp32<5, 5, 4, 1, 4>(240),
-    make_entry_wp32<6, 3, 4, 1, 8>(241),
-    make_entry_wp32<7, 4, 4, 1, 8>(242),
-    make_entry_wp32<8, 4, 4, 1, 8>(243),
-    make_entry_wp32<9, 5, 4, 1, 4>(244),
+    make_entry_wp32<5, 3, 1, 1, 8>(240),
+    make_entry_wp32<6, 3, 1, 1, 8>(241),
+    make_entry_wp32<7, 4, 1, 1, 8>(242),
+    make_entry_wp32<8, 4, 1, 1, 8>(243),
+    make_entry_wp32<9, 4, 1, 1, 8>(244),
 #ifdef AGX_DIAG
-    // A/B shapes
-    make_entry_wp32<5, 3, 4, 2, 8>(235),      // n = 32: 8 x 4
-    make_entry_wp32<9, 4, 4, 2, 8>(236),      // n = 512: 16 x 32 (three passes)
-    make_entry_wp32<7, 5, 4, 2, 4>(237),      // n = 128: 32 x 4
-    make_entry_wp32<8, 5, 4, 2, 4>(238),      // n = 256: 32 x 8
-    make_entry_wp32<6, 4, 4, 2, 8>(239),      // n = 64: 16 x 4
+    // A/B shapes (profiles/r04_small_sizes_sweeps.txt; 237-239 measured there and deleted)
+    make_entry_wp32<5, 5, 4, 2, 4>(235),      // n = 32: ONE LANE per frame, the whole transform in 32 registers, every twiddle a scalar: -7 %
+    make_entry_wp32<9, 5, 4, 2, 4>(236),      // n = 512: 32 x 16
 #endif
 };
 }  // namespace AGX_TU

@@ -775,8 +775,7 @@ REGISTRY = [
     (209, 256, 60), (210, 256, 61), (211, 256, 62), (212, 512, 60), (213, 512, 61), (214, 512, 62),
     (230, 32, 30), (231, 64, 30), (232, 128, 30), (233, 256, 30), (234, 512, 30), (240, 32, 31), (241, 64, 31), (242, 128, 31), (243, 256, 31), (244, 512, 31),
     # A/B shapes of the wave-packed kernels (lib/libagxntt_diag.so)
-    (215, 32, 60), (216, 64, 60), (217, 128, 60), (218, 256, 60), (219, 256, 60), (220, 512, 60), (221, 512, 60), (222, 256, 60), (223, 256, 60), (224, 32, 60), (225, 512, 60), (226, 256, 60),
-    (235, 32, 30), (236, 512, 30), (237, 128, 30), (238, 256, 30), (239, 64, 30),
+    (215, 32, 60), (220, 512, 60), (221, 512, 60), (222, 256, 60), (224, 32, 60), (235, 32, 30), (236, 512, 30),
 ]
 
 

@@ -24,6 +24,9 @@ ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--bits", type=int, default=60, help="modulus size in bits")
 ap.add_argument("--oop", action="store_true", help="forward / inverse out of place (slab i -> slab i+1)")
 ap.add_argument("--variant", type=int, default=None, help="registry id (AGX_VARIANT_REGBLOCK_BASE + id)")
+ap.add_argument("--ramp-seconds", type=float, default=0.5, help="run the operation this long before the warm-up launches so the GPU clock has ramped, as bench.py does (0 = cold)")
+ap.add_argument("--mulsets", type=int, default=0, help="mul: K rotating (a, b) operand sets, c and scratch separate (bench.py's n = 32768 product line); 0 = c aliases a on the slabs")
+ap.add_argument("--report", type=str, default=None, help="write {calls: ramp + warm-up + timed launches, ms: ...} here (tools/summarize_ops.py)")
 args = ap.parse_args()
 plan = agx.Plan(args.n, agx.find_primes(args.bits, args.n, args.primes))
 if args.variant is not None:
@@ -34,9 +37,20 @@ slabs = [torch.empty(per, dtype=torch.int64, device="cuda") for _ in range(args.
 for i, s in enumerate(slabs):
     plan.fill_synthetic(s.data_ptr(), args.batch, i * args.batch, 42, stream)
 scratch = torch.empty(per, dtype=torch.int64, device="cuda")
+sets, cbuf = [], None
+if args.op == "mul" and args.mulsets:
+    sets = [[torch.empty(per, dtype=torch.int64, device="cuda") for _ in range(2)] for _ in range(args.mulsets)]
+    for k, (a, b) in enumerate(sets):
+        plan.fill_synthetic(a.data_ptr(), args.batch, 2 * k * args.batch, 42, stream)
+        plan.fill_synthetic(b.data_ptr(), args.batch, (2 * k + 1) * args.batch, 42, stream)
+    cbuf = torch.empty(per, dtype=torch.int64, device="cuda")
 
 
 def run(i):
+    if sets:
+        a, b = sets[i % len(sets)]
+        plan.polymul(a.data_ptr(), b.data_ptr(), cbuf.data_ptr(), scratch.data_ptr(), args.batch, stream)
+        return
     a, b = slabs[i % args.slabs], slabs[(i + 1) % args.slabs]
     dst = b if args.oop else a
     if args.op == "fwd":
@@ -47,8 +61,18 @@ def run(i):
         plan.polymul(a.data_ptr(), b.data_ptr(), a.data_ptr(), scratch.data_ptr(), args.batch, stream)
 
 
+import time  # noqa: E402
+
+calls = 0
+t_end = time.perf_counter() + args.ramp_seconds
+while time.perf_counter() < t_end:      # clock ramp (bench.py: the first ~100 ms of work after an idle period run ~10 % slower)
+    for i in range(16):
+        run(calls)
+        calls += 1
+    torch.cuda.synchronize()
 for i in range(5):
     run(i)
+calls += 5
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -57,5 +81,10 @@ for i in range(args.launches):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.launches
+calls += args.launches
+if args.report:
+    import json
+
+    json.dump({"calls": calls, "timed": args.launches, "ms_per_launch": ms}, open(args.report, "w"))
 print(f"{args.op} n={args.n} primes={args.primes} batch={args.batch}: {ms:.4f} ms per launch, {args.primes * args.batch / ms / 1e3:.2f} M units/s")
 plan.close()

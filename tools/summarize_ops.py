@@ -14,9 +14,42 @@ import os
 import re
 import sys
 
-tag = sys.argv[1]
+import json
+
+argv = sys.argv[1:]
+bench = None
+if "--bench" in argv:      # a bench.py JSON line of the same box: its secondary kernel_ms beside the profiler's
+    i = argv.index("--bench")
+    try:
+        bench = json.load(open(argv[i + 1]))
+    except (OSError, ValueError):
+        bench = None
+    del argv[i:i + 2]
+table_name = None
+if "--table" in argv:      # name of the one-row-per-operation table (default TAG_ops_table.md): several box sessions of one TAG keep separate tables
+    i = argv.index("--table")
+    table_name = argv[i + 1]
+    del argv[i:i + 2]
+tag = argv[0]
 root = os.path.join("gpurun_out", f"prof_{tag}")
-ops = sys.argv[2:] or sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+ops = argv[1:] or sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+# profile op -> name of the bench line that times the same launch shape
+BENCH_LINE = {"fwd4096": None, "inv4096": "inverse_n4096", "mul4096": "polymul_n4096", "fwd16384": "forward_n16384_config4_slice", "inv16384": "inverse_n16384_config4_slice",
+              "fwd32768oop": "forward_n32768", "inv32768": "inverse_n32768", "mul32768": "polymul_n32768_config5_slice", "fwd1024q30": "forward_n1024_30bit",
+              "fwd4096q30": "forward_n4096_30bit", "inv4096q30": "inverse_n4096_30bit", "mul4096q30": "polymul_n4096_30bit", "fwd32": "forward_n32", "inv32": "inverse_n32",
+              "mul32": "polymul_n32", "fwd256": "forward_n256", "fwd512": "forward_n512", "inv512": "inverse_n512", "mul512": "polymul_n512", "fwd32q30": "forward_n32_30bit",
+              "fwd512q30": "forward_n512_30bit"}
+
+
+def bench_ms(op):
+    if not bench:
+        return None
+    if op == "fwd4096":
+        return bench.get("roofline", {}).get("kernel_ms")
+    for e in bench.get("secondary", []):
+        if e.get("name") == BENCH_LINE.get(op):
+            return e.get("kernel_ms")
+    return None
 SKIP = ("fill_kernel", "__amd_rocclr", "copyBuffer", "fillBuffer")
 
 
@@ -32,7 +65,7 @@ def parse_args(s):
             "bits": int(g("--bits", 60)), "oop": "--oop" in a}
 
 
-table = ["| op | kernel(s) | avg µs per launch (sum) | frac of 8 TB/s | HBM bytes ÷ algorithmic | VALU / butterfly | WAIT_ANY share | WAIT_INST_ANY share | VGPR | scratch B | profile |", "|---|---|---|---|---|---|---|---|---|---|---|"]
+table = ["| op | kernel(s) | avg µs per launch (sum) | bench.py kernel µs (same box) | profiler ÷ bench | frac of 8 TB/s | HBM bytes ÷ algorithmic | VALU / butterfly | WAIT_ANY share | WAIT_INST_ANY share | VGPR | scratch B | profile |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 sha = ""
 try:
     sha = open(os.path.join(root, "kernel_source_sha16.txt")).read().strip()
@@ -64,9 +97,14 @@ for op in ops:
         by = collections.defaultdict(list)
         for r in rows:
             by[r["Kernel_Name"]].append(r)
-        # launches per timed step of each kernel = its dispatch count / (5 warm-up + 100 timed)
+        # launches per timed step of each kernel = its dispatch count / (clock ramp + 5 warm-up + 100 timed launches of the operation)
+        calls = 105
+        try:
+            calls = json.load(open(os.path.join(d, "trace_report.json")))["calls"]
+        except (OSError, ValueError, KeyError):
+            pass
         for name, rs in by.items():
-            per_step = max(1, round(len(rs) / 105))
+            per_step = max(1, round(len(rs) / calls))
             last = rs[-100 * per_step:]
             dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
             kern[name] = {"calls": len(rs), "per_step": per_step, "avg_ns": sum(dur) / len(dur), "min_ns": min(dur), "max_ns": max(dur),
@@ -143,11 +181,15 @@ for op in ops:
         lines.append(f"- SQ_WAIT_ANY / SQ_WAVE_CYCLES = {wait_any / wave_cyc:.3f}; SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {wait_inst / wave_cyc:.3f}")
     open(os.path.join("profiles", f"{tag}_{op}_summary.md"), "w").write("\n".join(lines) + "\n")
     first = next(iter(kern.values()))
-    table.append(f"| {op} | {', '.join('`' + short(nm).split('::')[-1].split('<')[0] + '`' for nm in kern)} | {step_ns / 1e3:.1f} | {frac:.3f} | "
+    bms = bench_ms(op)
+    if bms:
+        lines += ["", f"bench.py on the same box (`secondary.kernel_ms` of `{BENCH_LINE.get(op) or 'the headline'}`): {bms * 1e3:.1f} µs per launch; profiler ÷ bench = {step_ns / 1e3 / (bms * 1e3):.3f}."]
+        open(os.path.join("profiles", f"{tag}_{op}_summary.md"), "a").write("\n".join(lines[-2:]) + "\n")
+    table.append(f"| {op} | {', '.join('`' + short(nm).split('::')[-1].split('<')[0] + '`' for nm in kern)} | {step_ns / 1e3:.1f} | {'%.1f' % (bms * 1e3) if bms else 'n/a'} | {'%.3f' % (step_ns / 1e3 / (bms * 1e3)) if bms else 'n/a'} | {frac:.3f} | "
                  f"{'%.3f' % ratio if ratio is not None else 'n/a'} | {'%.1f' % vpb if vpb else 'n/a'} | "
                  f"{'%.2f' % (wait_any / wave_cyc) if wave_cyc else 'n/a'} | {'%.2f' % (wait_inst / wave_cyc) if wave_cyc else 'n/a'} | "
                  f"{'/'.join(k['vgpr'] for k in kern.values())} | {'/'.join(k['scratch'] for k in kern.values())} | `profiles/{tag}_{op}_summary.md` |")
     print(f"{op}: {step_ns / 1e3:.1f} us/step frac {frac:.3f} traffic ratio {ratio} valu/bfly {vpb}")
 
-open(os.path.join("profiles", f"{tag}_ops_table.md"), "w").write(
+open(os.path.join("profiles", table_name or f"{tag}_ops_table.md"), "w").write(
     f"# `{tag}`: counters behind every secondary line (tools/profile_ops.sh, tools/summarize_ops.py; kernel sources sha16 `{sha}`)\n\n" + "\n".join(table) + "\n")
