@@ -66,10 +66,39 @@ uint32_t* plan_ticket_for(void* ctx, hipStream_t s) {
     if (s == hipStreamPerThread) return nullptr;
     std::lock_guard<std::mutex> lock(p->ticket_mu);
     for (size_t i = 0; i < p->ticket_streams.size(); ++i)
-        if (p->ticket_streams[i] == s) return p->d_ticket + 2 * i;
-    if (p->ticket_streams.size() >= kTicketSlots) return nullptr;
-    p->ticket_streams.push_back(s);
-    return p->d_ticket + 2 * (p->ticket_streams.size() - 1);
+        if (p->ticket_streams[i] == s) {
+            p->ticket_pending[i] = 1;
+            return p->d_ticket + 2 * i;
+        }
+    size_t slot = p->ticket_streams.size();
+    if (slot >= kTicketSlots) {
+        // every slot is taken: one whose stream's latest ticket launch has completed is idle -- its pair is zero again -- and can change hands
+        slot = kTicketSlots;
+        for (size_t i = 0; i < kTicketSlots && slot == kTicketSlots; ++i)
+            if (!p->ticket_pending[i] && p->ticket_events[i] && hipEventQuery(p->ticket_events[i]) == hipSuccess) slot = i;
+        if (slot == kTicketSlots) return nullptr;      // all busy: the stateless kernels
+        p->ticket_streams[slot] = s;
+    } else {
+        p->ticket_streams.push_back(s);      // capacity reserved at plan creation: no allocation here
+    }
+    if (!p->ticket_events[slot] && hipEventCreateWithFlags(&p->ticket_events[slot], hipEventDisableTiming) != hipSuccess) {
+        p->ticket_events[slot] = nullptr;      // without an event the slot can never be proven idle: it simply stays with this stream
+    }
+    p->ticket_pending[slot] = 1;
+    return p->d_ticket + 2 * slot;
+}
+
+void plan_ticket_launched(void* ctx, hipStream_t s, uint32_t* pair) {
+    const agx_ntt_plan* p = static_cast<const agx_ntt_plan*>(ctx);
+    if (!pair || !p->d_ticket) return;
+    const size_t slot = (size_t)(pair - p->d_ticket) / 2;
+    std::lock_guard<std::mutex> lock(p->ticket_mu);
+    if (slot >= p->ticket_events.size()) return;
+    if (p->ticket_events[slot] && hipEventRecord(p->ticket_events[slot], s) != hipSuccess) {
+        (void)hipEventDestroy(p->ticket_events[slot]);
+        p->ticket_events[slot] = nullptr;
+    }
+    p->ticket_pending[slot] = 0;
 }
 
 plan_view view_of(const agx_ntt_plan* p) {
@@ -84,6 +113,7 @@ plan_view view_of(const agx_ntt_plan* p) {
     v.tw_rb = p->d_tw_rb;
     v.itw_rb = p->d_itw_rb;
     v.ticket_for = &plan_ticket_for;
+    v.ticket_launched = &plan_ticket_launched;
     v.ticket_ctx = const_cast<agx_ntt_plan*>(p);
     return v;
 }
@@ -111,6 +141,8 @@ void free_plan(agx_ntt_plan* p) {
     if (!p) return;
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (p->d_ticket) (void)hipFree(p->d_ticket);
+    for (hipEvent_t ev : p->ticket_events)
+        if (ev) (void)hipEventDestroy(ev);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_itw) (void)hipFree(p->d_itw);
     if (p->d_tw_rb) (void)hipFree(p->d_tw_rb);
@@ -207,6 +239,8 @@ int instantiate_plan(agx_ntt_plan** out, const plan_image& img) {
     p->rb = img.rb;
     p->rb_fwd = img.rb_fwd;
     p->ticket_streams.reserve(kTicketSlots);      // plan_ticket_for() runs inside unguarded launch calls: it must never allocate
+    p->ticket_events.assign(kTicketSlots, nullptr);
+    p->ticket_pending.assign(kTicketSlots, 0);
     p->moduli = img.moduli;
     p->psi = img.psi;
     int rc = AGX_OK;

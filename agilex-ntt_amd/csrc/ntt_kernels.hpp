@@ -38,8 +38,10 @@ struct plan_view {
     // only if they need one: the pair is keyed by the stream (launches on one stream serialise, so they may share a pair; the last
     // workgroup out zeroes it).  nullptr = no pair can be proven free (too many distinct streams): take the stateless fixed-stride form.
     uint32_t* (*ticket_for)(void* ctx, hipStream_t s) = nullptr;
+    void (*ticket_launched)(void* ctx, hipStream_t s, uint32_t* pair) = nullptr;      // right behind the launch that uses `pair`: marks when the pair will be idle again
     void* ticket_ctx = nullptr;
     uint32_t* ticket(hipStream_t s) const { return ticket_for ? ticket_for(ticket_ctx, s) : nullptr; }
+    void ticket_done(hipStream_t s, uint32_t* pair) const { if (ticket_launched) ticket_launched(ticket_ctx, s, pair); }
 };
 
 struct frame_layout {

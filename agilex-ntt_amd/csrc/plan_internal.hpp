@@ -31,15 +31,19 @@ struct agx_ntt_plan {
     agx::regblock_layout rb;
     agx::regblock_layout rb_fwd;            // forward-only layout (another kernel shape that is faster for the forward transform), or invalid
     ulonglong2* d_tw_rb_fwd = nullptr;
-    // {next frame, retired workgroups} pairs for the kernels that hand out frames dynamically (the loop kernels of n >= 16384; diag
-    // ids 83/84), one pair per STREAM: launches on one stream run one after the other, and the last workgroup of a launch zeroes the
+    // {next frame, retired workgroups} pairs for the kernels that hand out frames dynamically (the inverse loop kernels of n >= 16384),
+    // one pair per STREAM: launches on one stream run one after the other, and the last workgroup of a launch zeroes the
     // pair, so a stream's launches can share one; launches on different streams get different pairs.  Only a launcher that needs a
-    // pair asks for one (plan_view::ticket).  A stream beyond the kTicketSlots-th gets none and its launches take the stateless
-    // fixed-stride kernels.  A slot is never recycled (a destroyed stream's handle may be reused by a new stream: that is still ONE
-    // stream at a time, so sharing its pair stays safe).
+    // pair asks for one (plan_view::ticket).  When all kTicketSlots are taken, a new stream gets the slot of a stream whose latest ticket
+    // launch has provably completed (its event has fired: the pair is idle and zero); if there is none, no pair: the stateless fixed-stride
+    // kernels (slots used to be claimed for good, so a long-lived plan used with short-lived streams ended up on the slower form).
     uint32_t* d_ticket = nullptr;
     mutable std::mutex ticket_mu;
     mutable std::vector<hipStream_t> ticket_streams;
+    // slot i: an event recorded behind the stream's latest ticket launch (once it has completed the pair reads {0, 0} again: the last
+    // workgroup out zeroes it), and whether a launch that took the slot has not recorded its event yet
+    mutable std::vector<hipEvent_t> ticket_events;
+    mutable std::vector<char> ticket_pending;
 };
 
 

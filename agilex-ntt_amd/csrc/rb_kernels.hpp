@@ -485,18 +485,20 @@ template <int L, int R, int ARITH, int MINW>
 hipError_t launch_inv_rb2_dloop_t(const plan_view& pv, const uint64_t* in, const uint64_t* in2, uint64_t* out, const frame_layout& fl, hipStream_t s) {
     using G = rb_geom<L, R>;
     if (stream_is_capturing(s)) return launch_inv_rb2_loop_t<L, R, ARITH, MINW>(pv, in, in2, out, fl, s);
-    uint32_t* ticket = pv.ticket(s);
-    if (!ticket) return launch_inv_rb2_loop_t<L, R, ARITH, MINW>(pv, in, in2, out, fl, s);      // no pair provably free: stateless form
     unsigned resident = 0;
     hipError_t e = resident_workgroups<L, R, MINW>(&resident);
     if (e != hipSuccess) return e;
     const uint64_t total = fl.batch * pv.num_primes;
     if (total >= (1ull << 31)) return hipErrorInvalidValue;
+    uint32_t* ticket = pv.ticket(s);      // taken last: from here on the launch is issued and ticket_done() follows it
+    if (!ticket) return launch_inv_rb2_loop_t<L, R, ARITH, MINW>(pv, in, in2, out, fl, s);      // no pair provably free: stateless form
     const unsigned grid = (unsigned)(total < resident ? total : resident);
     const size_t lds = rb2_lds_bytes<L, R, 1, ARITH>() + 16;
     hipLaunchKernelGGL((inv_rb2_dloop<L, R, ARITH, MINW>), dim3(grid), dim3(G::T), lds, s, in, in2, out, pv.consts, pv.itw_rb,
                        pv.rb.pairs_per_prime, (uint32_t)fl.batch, (uint32_t)total, fl.prime_stride, fl.poly_stride, ticket);
-    return hipGetLastError();
+    e = hipGetLastError();
+    pv.ticket_done(s, ticket);      // an event behind the launch: when it has fired the pair is idle (and zero) and the plan may hand it to another stream
+    return e;
 }
 
 // the streamed single-frame kernels (reg_s<n>.hip): one frame in registers per workgroup at any time (R = 5: a second frame cannot

@@ -13,6 +13,7 @@ const rb_entry kEntries[] = {
     make_entry_single<15, 5, kExact, 4>(123),
 #ifdef AGX_DIAG
     make_entry_single<15, 5, kLazy, 4>(114),      // A/B twin: the inverse one workgroup per frame too
+    make_entry_single<15, 6, kLazy, 2>(126),      // A/B: 512 threads x 64 coefficients (8-wave barriers, 2 waves/SIMD)
 #endif
 };
 }  // namespace AGX_TU

@@ -2,7 +2,7 @@
 // smoke driver (src/main.cpp:14-89 there) with real tables and known answers instead of
 // placeholders.  `make run` builds and runs it.
 //
-// Checks, for n = 1024 (30-bit q), n = 4096 / 16384 / 32768 (60-bit q) and n = 16384 under the reference's own 17-bit modulus 65537:
+// Checks, for n = 32 (30- and 60-bit q), n = 512 (60-bit), n = 1024 (30-bit q), n = 4096 / 16384 / 32768 (60-bit q) and n = 16384 under the reference's own 17-bit modulus 65537:
 //   NTT(delta_0) = (1,...,1);  NTT(X)[bitrev(k)] = psi^(2k+1);  INTT(NTT(x)) = x on random x;
 // the reference's operand pairing with inData2 != inData (src/kernel/ntt.cpp:584-590); and the convolution theorem against the
 // schoolbook product mod X^n + 1 (n = 64 and 1024).
@@ -252,7 +252,8 @@ int main(int argc, char** argv) {
     }
     if (!devices.empty()) return scaling_mode(devices, small, steps);
     // 17 bits: the modulus class of the reference's own smoke driver (65537, src/main.cpp:55) -> the 32-bit arithmetic kernels
-    int fail = run_case(1024, 30) | run_case(4096, 60) | run_case(16384, 60) | run_case(32768, 60) | run_case(16384, 17);
+    // n = 32 is the smallest size of the reference's table (include/kernel/ntt.h:11-12): the wave-packed kernels (several frames per wave)
+    int fail = run_case(32, 30) | run_case(32, 60) | run_case(512, 60) | run_case(1024, 30) | run_case(4096, 60) | run_case(16384, 60) | run_case(32768, 60) | run_case(16384, 17);
     fail |= run_pairing_case(1024, 30) | run_pairing_case(16384, 60);
     fail |= run_schoolbook_case(64, 30) | run_schoolbook_case(64, 60) | run_schoolbook_case(1024, 30);
     std::printf(fail ? "HARNESS FAILED\n" : "HARNESS PASSED\n");

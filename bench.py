@@ -79,7 +79,7 @@ def cpu_baseline(target_seconds=12.0):
 
 class PowerSampler:
     """Socket power and shader clock of the bench GPU from amdgpu's sysfs files (hwmon power1_average/_input in microwatts,
-    pp_dpm_sclk's starred level), sampled every 20 ms by a daemon thread while the steps run.  Evidence only: whether the
+    pp_dpm_sclk's starred level), sampled every 5 ms by a daemon thread while the steps run (the shortest secondary line is ~50 ms: >= 10 samples).  Evidence only: whether the
     part sits at its power cap on this instruction mix (profiles/r02a_clock_power.txt); never part of `value`."""
 
     def __init__(self, torch, index):
@@ -126,7 +126,7 @@ class PowerSampler:
     def _run(self):
         while not self._stop.is_set():
             self.samples.append((time.perf_counter(),) + self._read())
-            self._stop.wait(0.02)
+            self._stop.wait(0.005)
 
     def window(self, t0, t1):
         """samples taken in [t0, t1] (perf_counter times) -> summary dict or None"""
@@ -143,7 +143,7 @@ class PowerSampler:
         return {"samples": len(pick), "socket_power_w_median": watts[len(watts) // 2] if watts else None,
                 "socket_power_w_max": watts[-1] if watts else None, "power_cap_w": cap,
                 "sclk_mhz_median": mhz[len(mhz) // 2] if mhz else None, "sclk_mhz_max_level": 2400,
-                "source": "amdgpu sysfs (hwmon power1_*, pp_dpm_sclk), 20 ms period, while the ramp + warm-up + timed steps ran"}
+                "source": "amdgpu sysfs (hwmon power1_*, pp_dpm_sclk), 5 ms period, while the ramp + warm-up + timed steps ran"}
 
     def median_w(self, t0, t1):
         watts = sorted(s[1] for s in self.samples if t0 <= s[0] <= t1 and s[1] is not None)

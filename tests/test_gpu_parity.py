@@ -1125,8 +1125,8 @@ def test_out_of_contract_tables_stay_on_the_exact_kernels(agx, orc, dev):
 
 
 def test_more_streams_than_ticket_slots(agx, orc, dev):
-    """a plan keeps one {ticket, retired} pair per stream for 64 streams; launches on further streams must take the stateless
-    fixed-stride kernels -- every result right, on 70 streams of one plan, twice (a wrapped ticket ring let two
+    """a plan keeps one {ticket, retired} pair per stream for 64 streams; launches on further streams take over the pair of a stream
+    whose launches have completed, or the stateless fixed-stride kernels -- every result right, on 70 streams of one plan, twice (a wrapped ticket ring let two
     launches in flight share one counter and skip frames silently)"""
     import torch
 
@@ -1156,6 +1156,17 @@ def test_more_streams_than_ticket_slots(agx, orc, dev):
             plan.inverse(b.data_ptr(), b.data_ptr(), batch, st.cuda_stream)
             st.synchronize()
             assert np.array_equal(dev.to_host(b), want), (rep, i)
+    # 70 launches IN FLIGHT together, one per stream, each on its own buffer: a slot may only change hands when its previous stream's
+    # launch has completed (round 4: slots are recycled through an event recorded behind every ticket launch), so no two running
+    # launches may ever share a pair
+    for rep in range(2):
+        bufs = [dev.to_device(r) for _ in streams]
+        dev.sync()
+        for b, st in zip(bufs, streams):
+            plan.inverse(b.data_ptr(), b.data_ptr(), batch, st.cuda_stream)
+        dev.sync()
+        for i, b in enumerate(bufs):
+            assert np.array_equal(dev.to_host(b), want), ("concurrent", rep, i)
     plan.close()
 
 
