@@ -28,7 +28,7 @@ struct shard {
     std::condition_variable cv;
     std::function<int()> job;
     bool has_job = false, done = false, quit = false;
-    int result = AGX_OK;
+    int result = AGX_OK, hip_error = 0;      // hip_error: this worker's agx_ntt_last_hip_error() after the job (thread-local: the caller cannot see it otherwise)
 
     void loop() {
         const bool dev_ok = hipSetDevice(device) == hipSuccess;
@@ -42,6 +42,7 @@ struct shard {
             int rc = dev_ok ? guarded(j) : AGX_ERR_HIP;
             lk.lock();
             result = rc;
+            hip_error = last_hip_error_slot();
             done = true;
             cv.notify_all();
         }
@@ -100,7 +101,10 @@ int on_every_shard(const agx_ntt_group* cg, F&& fn) {
     int rc = AGX_OK;
     for (size_t i = 0; i < g->shards.size(); ++i) {
         const int r = g->shards[i]->wait();
-        if (rc == AGX_OK) rc = r;
+        if (rc == AGX_OK && r != AGX_OK) {
+            rc = r;
+            last_hip_error_slot() = g->shards[i]->hip_error;      // agx_ntt_last_hip_error() on the caller's thread names the failing shard's HIP error
+        }
     }
     return rc;
 }

@@ -28,6 +28,7 @@ using namespace agx;
 thread_local int g_last_hip_error = 0;
 
 namespace agx {
+int& last_hip_error_slot() { return g_last_hip_error; }
 int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;
     return e == hipErrorOutOfMemory ? AGX_ERR_ALLOC : AGX_ERR_HIP;

@@ -50,6 +50,7 @@ struct agx_ntt_plan {
 namespace agx {
 
 int hip_fail(hipError_t e);      // records the HIP error for agx_ntt_last_hip_error() and maps it to a status
+int& last_hip_error_slot();      // this thread's agx_ntt_last_hip_error() value (a group copies its failing shard's into the caller's)
 
 #define AGX_HIP(expr)                                    \
     do {                                                 \

@@ -13,7 +13,8 @@ const rb_entry kEntries[] = {
     make_entry_single<15, 5, kExact, 4>(123),
 #ifdef AGX_DIAG
     make_entry_single<15, 5, kLazy, 4>(114),      // A/B twin: the inverse one workgroup per frame too
-    make_entry_single<15, 6, kLazy, 2>(126),      // A/B: 512 threads x 64 coefficients (8-wave barriers, 2 waves/SIMD)
+    // (512 threads x 64 coefficients -- R = 6, 205 VGPRs, 2 waves/SIMD, 8-wave barriers -- measured in round 4 and deleted: 31.1 vs 35.6 % of 8 TB/s,
+    // profiles/r04_sweep_32768_r6.txt)
 #endif
 };
 }  // namespace AGX_TU

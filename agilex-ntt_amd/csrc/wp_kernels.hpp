@@ -46,8 +46,8 @@ struct wp_geom {
     }
 };
 
-// one wave's coefficients from layout FROM to layout TO through its part of the LDS image (WORD = uint64_t: 64-bit image;
-// with SPLIT the low and the high 32-bit words in turn through an image of half the size; WORD = uint32_t: the 32-bit kernels).
+// one wave's coefficients from layout FROM to layout TO through its part of the LDS image (64-bit words; with SPLIT the low and the
+// high 32-bit words in turn through an image of half the size; wp_relayout32 below: the 32-bit kernels' image).
 // The leading fence orders this wave's earlier LDS reads of the same words (an exchange, the previous operand's staging).
 template <int L, int R, int FROM, int TO, int PADS, bool SPLIT>
 __device__ __forceinline__ void wp_relayout(uint64_t (&x)[1 << R], void* wimg, uint32_t lane) {
