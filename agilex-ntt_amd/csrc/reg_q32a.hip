@@ -12,8 +12,10 @@
 namespace agx {
 namespace AGX_TU {
 const rb_entry kEntries[] = {
-    make_entry_q32<10, 4, 4, 2, 8>(130),     // one wave per frame: no workgroup barrier at all
-    make_entry_q32<11, 4, 2, 2, 8>(131),
+    // one frame per workgroup at every size: at n = 1024 (one wave per frame: no workgroup barrier at all) and n = 2048 a workgroup used to hold
+    // four / two frames; a frame that retires alone frees its slot at once: +5 % forward, +1 ... 2 % inverse and product (profiles/r04_q32_one_frame_per_workgroup.txt)
+    make_entry_q32<10, 4, 1, 2, 8>(130),
+    make_entry_q32<11, 4, 1, 2, 8>(131),
     make_entry_q32<12, 4, 1, 2, 8>(132),
     make_entry_q32<13, 4, 1, 2, 8>(133),
     make_entry_q32<14, 4, 1, 2, 8>(134),     // 68 KiB image: two 1024-thread workgroups per CU

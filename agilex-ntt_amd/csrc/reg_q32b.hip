@@ -12,8 +12,8 @@
 namespace agx {
 namespace AGX_TU {
 const rb_entry kEntries[] = {
-    make_entry_q32<10, 4, 4, 1, 8>(136),
-    make_entry_q32<11, 4, 2, 1, 8>(137),
+    make_entry_q32<10, 4, 1, 1, 8>(136),
+    make_entry_q32<11, 4, 1, 1, 8>(137),
     make_entry_q32<12, 4, 1, 1, 8>(138),
     make_entry_q32<13, 4, 1, 1, 8>(139),
     make_entry_q32<14, 4, 1, 1, 8>(140),
