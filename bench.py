@@ -155,24 +155,30 @@ class PowerSampler:
             self._thread.join(timeout=1.0)
 
 
-def _timed(torch, fn, launches, warmup):
-    """average duration (ms) of `launches` back-to-back calls of fn(i) after `warmup` untimed ones,
-    measured with events on the launch stream"""
+def _timed(torch, fn, launches, warmup, min_window_ms=60.0):
+    """average duration (ms) of `launches` back-to-back calls of fn(i) after `warmup` untimed ones, measured with events on the
+    launch stream; a line whose timed region would be shorter than min_window_ms is timed again with proportionally more launches, so
+    that the power sampler (5 ms period) sees at least ~10 samples of it"""
     for i in range(warmup):
         fn(i)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    _timed.window = [time.perf_counter(), None]
-    e0.record()
-    for i in range(launches):
-        fn(warmup + i)
-    e1.record()
-    torch.cuda.synchronize()
-    _timed.window[1] = time.perf_counter()
-    return e0.elapsed_time(e1) / launches
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _timed.window = [time.perf_counter(), None]
+        e0.record()
+        for i in range(launches):
+            fn(warmup + i)
+        e1.record()
+        torch.cuda.synchronize()
+        _timed.window[1] = time.perf_counter()
+        total = e0.elapsed_time(e1)
+        _timed.launches = launches
+        if total >= min_window_ms or launches >= 20000:
+            return total / launches
+        launches = int(launches * min_window_ms / max(total, 1e-3) * 1.1) + 1
 
 
-PROFILE_TAG = "r04"       # the committed per-operation counter summaries the secondary lines point at
+PROFILE_TAG = "r04f"      # the committed per-operation counter summaries the secondary lines point at
 
 
 def per_slab_elems(slabs):
@@ -189,7 +195,7 @@ def secondary_lines(torch, agx, plan4096, slabs, batch, stream, sampler=None, id
     def entry(name, workload, units, bytes_per_unit, ms, unit, launches, note=None, profile=None):
         gbs = units * bytes_per_unit / (ms * 1e-3) / 1e9
         e = {"name": name, "workload": workload, "value": units / (ms * 1e-3), "unit": unit, "kernel_ms": ms,
-             "launches_timed": launches, "algorithmic_bytes_per_launch": units * bytes_per_unit,
+             "launches_timed": getattr(_timed, "launches", launches), "algorithmic_bytes_per_launch": units * bytes_per_unit,
              "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
         if note:
             e["note"] = note
