@@ -221,3 +221,35 @@ def test_harness_scaling_mode_on_two_shards(agx):
     assert "SCALING PASSED" in r.stdout and "FAIL" not in r.stdout, r.stdout[-3000:]
     assert r.stdout.count("== one device") == 3 and r.stdout.count("shard 1 (device 0)") == 2 and r.stdout.count("aggregate:") == 2, r.stdout[-3000:]
     print(r.stdout)
+
+
+def test_group_calls_from_two_host_threads(agx, orc):
+    """calls on ONE group from two host threads serialise (include/agx_ntt.h: one call at a time per group), calls on two groups run
+    side by side; every result right, repeatedly"""
+    n, frames = 4096, 700
+    t = tables_for(orc, n, 60)[0]
+    g1 = agx.DeviceGroup([0, 0], n, [t[0]], psi=[t[1]])
+    g2 = agx.DeviceGroup([0], n, [t[0]], psi=[t[1]])
+    rng = np.random.default_rng(21)
+    xs = [rand_coeffs(rng, frames * n, t[0]) for _ in range(3)]
+    wants = [_oracle_forward(orc, x, t, n) for x in xs]
+    outs = [None] * 3
+    errs = []
+
+    def work(k, grp):
+        try:
+            for _ in range(3):
+                outs[k] = grp.forward_host(xs[k], xs[k], frames)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(0, g1)), threading.Thread(target=work, args=(1, g1)), threading.Thread(target=work, args=(2, g2))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for k in range(3):
+        assert np.array_equal(outs[k], wants[k]), k
+    g1.close()
+    g2.close()
