@@ -788,6 +788,36 @@ struct oneshot_cache {
     std::vector<uint64_t> tw, pre;     // host copies of the tables the cached plan was built from
 };
 oneshot_cache g_oneshot[kPoolDevices];
+
+// AGX_NTT_DEVICES=0,1,2,3 in the environment: the one-shot call deals its frames to those devices (a group, include/agx_ntt.h section 5)
+// instead of running on the current one -- the reference's NUM_NTT_COMPUTE_UNITS replication (src/kernel/ntt.cpp:8-12, 526-536) for a
+// caller that cannot change its code.  One cached group, rebuilt when (n, modulus, tables, device list) change.
+struct oneshot_group_cache {
+    std::mutex mu;
+    agx_ntt_group* group = nullptr;
+    uint32_t n = 0;
+    uint64_t q = 0;
+    std::vector<uint64_t> tw, pre;
+    std::vector<int> devices;
+};
+oneshot_group_cache g_oneshot_group;
+
+void env_device_list(std::vector<int>& out) {
+    out.clear();
+    const char* v = std::getenv("AGX_NTT_DEVICES");
+    if (!v || !*v) return;
+    for (const char* p = v; *p;) {
+        char* end = nullptr;
+        const long d = std::strtol(p, &end, 10);
+        if (end == p) {      // not a number: a device id the group will refuse
+            out.assign(1, -1);
+            return;
+        }
+        out.push_back((int)d);
+        p = end;
+        while (*p == ',' || *p == ' ') ++p;
+    }
+}
 }  // namespace
 
 int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
@@ -801,6 +831,26 @@ int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return AGX_ERR_NO_DEVICE;
     try {
+        std::vector<int> devices;
+        env_device_list(devices);
+        if (!devices.empty()) {
+            oneshot_group_cache& c = g_oneshot_group;
+            std::lock_guard<std::mutex> lock(c.mu);
+            const bool hit = c.group && c.n == n && c.q == modulus[0] && c.devices == devices &&
+                             std::memcmp(c.tw.data(), twiddles, (size_t)n * 8) == 0 && std::memcmp(c.pre.data(), precons, (size_t)n * 8) == 0;
+            if (!hit) {
+                agx_ntt_group* g = nullptr;
+                if ((rc = agx_ntt_group_create(&g, devices.data(), (uint32_t)devices.size(), n, 1, modulus, twiddles, precons, nullptr, nullptr))) return rc;
+                agx_ntt_group_destroy(c.group);
+                c.group = g;
+                c.n = n;
+                c.q = modulus[0];
+                c.tw.assign(twiddles, twiddles + n);
+                c.pre.assign(precons, precons + n);
+                c.devices = devices;
+            }
+            return agx_ntt_group_forward_host(c.group, in, in2, out, num_frames);
+        }
         if (dev < 0 || dev >= kPoolDevices) {      // no cache slot: build, use, destroy
             agx_ntt_plan* plan = nullptr;
             if ((rc = build_plan(&plan, n, 1, modulus, nullptr, twiddles, precons, nullptr, nullptr))) return rc;
@@ -833,6 +883,13 @@ int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t
 // (192 MiB pinned + 96 MiB device memory per device that has streamed host frames).  Call it before hipDeviceReset or at
 // shutdown; calls running at the same time keep what they hold (a busy staging set is skipped).  Later calls rebuild on demand.
 int agx_ntt_release_caches(void) {
+    {
+        std::lock_guard<std::mutex> lock(g_oneshot_group.mu);
+        agx_ntt_group_destroy(g_oneshot_group.group);      // joins its workers; each frees its shard on its own device
+        g_oneshot_group.group = nullptr;
+        g_oneshot_group.tw.clear();
+        g_oneshot_group.pre.clear();
+    }
     for (int d = 0; d < kPoolDevices; ++d) {
         {
             std::lock_guard<std::mutex> lock(g_oneshot[d].mu);

@@ -73,6 +73,9 @@ AGX_API int agx_ntt_device_count(int* count); /* AGX_OK and *count = 0 when ther
 /* runtime argument here (the reference fixes it at compile time,              */
 /* include/kernel/ntt.h:7-23).  Synchronous; all pointers are host memory.     */
 /* ------------------------------------------------------------------------- */
+/* With AGX_NTT_DEVICES=0,1,2,3 in the environment the frames are dealt to those devices in contiguous blocks (a group, section 5) instead */
+/* of running on the current one: the reference's NUM_NTT_COMPUTE_UNITS replication (src/kernel/ntt.cpp:8-12, 526-536) for a caller that  */
+/* cannot change its code; a device id that does not exist returns AGX_ERR_BAD_ARGUMENT.                                                  */
 AGX_API int agx_ntt_forward_host(const uint64_t* in, const uint64_t* in2, const uint64_t* modulus,
                          const uint64_t* twiddles, const uint64_t* precons, uint64_t* out,
                          uint32_t n, uint32_t num_frames);

@@ -253,3 +253,38 @@ def test_group_calls_from_two_host_threads(agx, orc):
         assert np.array_equal(outs[k], wants[k]), k
     g1.close()
     g2.close()
+
+
+def test_one_shot_call_over_a_device_list_from_the_environment(agx, orc):
+    """AGX_NTT_DEVICES=0,0: agx_ntt_forward_host -- the drop-in for the reference's three calls -- deals its frames to the listed devices
+    without a change in the caller (the reference's NUM_NTT_COMPUTE_UNITS replication, src/kernel/ntt.cpp:8-12, 526-536): same bits as
+    on one device, in2 != in included; a device that does not exist is status 5; the cached group follows the caller's tables"""
+    import os
+
+    n, frames = 4096, 900
+    t = tables_for(orc, n, 60)[0]
+    rng = np.random.default_rng(8)
+    x = rand_coeffs(rng, frames * n, t[0])
+    a, b = x.copy().reshape(frames, n), x.copy().reshape(frames, n)
+    a[:, n // 2:] = np.uint64(1)
+    b[:, :n // 2] = np.uint64(2)
+    want = _oracle_forward(orc, x, t, n)
+    old = os.environ.get("AGX_NTT_DEVICES")
+    try:
+        os.environ["AGX_NTT_DEVICES"] = "0,0"
+        assert np.array_equal(agx.forward_host(a.reshape(-1), b.reshape(-1), t[0], t[2], t[3], n, frames), want)
+        assert np.array_equal(agx.forward_host(x, x, t[0], t[2], t[3], n, frames), want)      # cached group
+        t2 = tables_for(orc, n, 59)[0]                                                         # other tables: the group is rebuilt
+        x2 = x % np.uint64(t2[0])
+        assert np.array_equal(agx.forward_host(x2, x2, t2[0], t2[2], t2[3], n, frames), _oracle_forward(orc, x2, t2, n))
+        os.environ["AGX_NTT_DEVICES"] = "0,77"
+        with pytest.raises(agx.AgxError) as ei:
+            agx.forward_host(x, x, t[0], t[2], t[3], n, frames)
+        assert ei.value.status == 5
+    finally:
+        if old is None:
+            os.environ.pop("AGX_NTT_DEVICES", None)
+        else:
+            os.environ["AGX_NTT_DEVICES"] = old
+        assert agx.lib().agx_ntt_release_caches() == 0
+    assert np.array_equal(agx.forward_host(x, x, t[0], t[2], t[3], n, frames), want)      # back on the current device

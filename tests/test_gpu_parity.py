@@ -412,7 +412,7 @@ def test_large_frames_fast_and_exact_forms(agx, orc, dev, n, bits):
     plan.close()
 
 
-@pytest.mark.parametrize("n,batch", [(4096, 8), (4096, 4200), (16384, 300)])
+@pytest.mark.parametrize("n,batch", [(32, 1000), (512, 77), (4096, 8), (4096, 4200), (16384, 300)])
 def test_calls_are_graph_capturable(agx, orc, dev, n, batch):
     """the device-pointer calls allocate nothing and never synchronise, so a stream capture can
     record them: forward + inverse captured once into a HIP graph, replayed on new data (n=16384 with more frames than
