@@ -451,8 +451,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    grp = agx.Group(backend="nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+    # AGX_BENCH_REHEARSAL=1: every rank on GPU 0 and the timing collectives over gloo (RCCL refuses two ranks on one GPU) -- the N > 1 control flow
+    # of this file (shard offsets, barriers, MAX over ranks, per_rank gather, one JSON line from rank 0) rehearsed on a one-GPU box.  The line says so
+    # ("rehearsal": true); its `value` is two ranks SHARING one GPU and is not a multi-GPU figure.
+    rehearsal = os.environ.get("AGX_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    grp = agx.Group(backend="gloo", device=None) if rehearsal else agx.Group(backend="nccl", device=torch.device("cuda", dev_index))   # "nccl" is RCCL on ROCm
     rank, world = grp.rank, grp.world
 
     batch = args.batch
@@ -485,7 +490,7 @@ def main():
     # follow unchanged.  The first barrier here also pays RCCL's communicator set-up outside the timing.
     grp.barrier()
     torch.cuda.synchronize()
-    sampler = PowerSampler(torch, local_rank)      # every rank samples its own GPU (per_rank below); rank 0's goes into `power`
+    sampler = PowerSampler(torch, dev_index)       # every rank samples its own GPU (per_rank below); rank 0's goes into `power`
     # idle socket power: 0.4 s with nothing queued, before the ramp (the baseline of energy_uj_per_ntt)
     t_idle0 = time.perf_counter()
     time.sleep(0.4)
@@ -560,6 +565,7 @@ def main():
             "n": N_COEFF, "primes": NUM_PRIMES, "batch_per_gpu": batch, "ntts_per_step_per_gpu": ntts_per_step_per_gpu,
             "slabs_rotated": NUM_SLABS, "clock_ramp_steps_before_warmup": ramp_steps, "parallelism": f"batch-sharded x{world}, no collective",
             "polys_per_sec": value / NUM_PRIMES,
+            **({"rehearsal": True, "rehearsal_note": f"{world} ranks on ONE GPU, timing collectives over gloo: exercises the N > 1 control flow, not a multi-GPU figure"} if rehearsal else {}),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
