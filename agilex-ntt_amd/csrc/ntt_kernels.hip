@@ -253,7 +253,7 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int 
     regblock_layout rb;
     int log_n = 0;
     while ((1u << log_n) < n) ++log_n;
-    if (log_n < 5) return rb;  // n < 32 stays on the radix-2 kernel
+    if (log_n < 1) return rb;
     // a 32-bit entry is legal when every modulus fits its tier and the tables honour the precon contract
     auto legal = [&](const rb_entry& c) { return c.arith <= arith_level && (c.narrow == 0 || (arith_level >= 1 && narrow_level >= (c.narrow == 2 ? 2 : 1))); };
     const rb_entry* e = nullptr;
@@ -262,7 +262,8 @@ regblock_layout regblock_choose(uint32_t n, int config_id, int arith_level, int 
         if (e && (e->log_n != log_n || !legal(*e))) e = nullptr;
     } else {
         // tuned defaults, best first; the lazier arithmetic forms only when every modulus allows them
-        static const int kDefaults[] = {230, 231, 232, 233, 234, 240, 241, 242, 243, 244,                 // n = 32 ... 512, narrow moduli: wave-packed 32-bit kernels (tier 2, then tier 1)
+        static const int kDefaults[] = {260, 261, 262, 263, 264, 265, 266, 267, 230, 231, 232, 233, 234, 240, 241, 242, 243, 244,      // n = 2 ... 512, narrow moduli: wave-packed 32-bit kernels (tier 2, then tier 1)
+                                        250, 251, 252, 253, 254, 255, 256, 257,                          // n = 2 ... 16: one lane per frame (fast, exact per size)
                                         200, 201, 202, 203, 204, 205, 206, 207, 208, 209, 210, 211, 212, 213, 214,      // n = 32 ... 512: wave-packed kernels (16q-lazy, fast, exact per size)
                                         130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141,      // narrow moduli: 32-bit arithmetic (tier 2, then tier 1)
                                         93, 92, 91,                                                      // n = 4096: R = 3, 8 waves/SIMD (16q-lazy, fast, exact)

@@ -101,7 +101,7 @@ template <int L, int R, int TIER>
 struct rb32_frame {
     using G = rb2_geom<L, R>;
     static constexpr int C = G::C, T = G::T, NP = G::NP;
-    static constexpr uint32_t slab_words = (1u << L) + (1u << (L - 5));
+    static constexpr uint32_t slab_words = (1u << L) + (L >= 5 ? (1u << (L >= 5 ? L - 5 : 0)) : 0u);
     // image word of coefficient e: one pad word per 32 (additive over disjoint bit fields: thread base + compile-time constant); of the
     // shifts 3..7 this one leaves the fewest bank conflicts for 32-bit accesses (32 banks per group of 32 lanes) at every (L, R) used here
     static __device__ __forceinline__ constexpr uint32_t img(uint32_t e) { return e + (e >> 5); }

@@ -214,7 +214,7 @@ struct rb2_frame {
     // 32-bit accesses see 32 banks per group of 32 lanes: with it every exchange pattern of the R = 5 kernels is conflict-free, with one
     // per 16 every one of them was two-way conflicted (SQ_LDS_BANK_CONFLICT 45 % of the LDS cycles, profiles/r03c_fwd4096_summary.md)
     static constexpr int PADS = (OPT & kOptSplitWord) != 0 ? 5 : 4;
-    static constexpr uint32_t slab_elems = (1u << L) + (1u << (L - PADS));
+    static constexpr uint32_t slab_elems = (1u << L) + (L >= PADS ? (1u << (L >= PADS ? L - PADS : 0)) : 0u);      // frames below 2^PADS coefficients (wave-packed kernels, one lane per frame) never exchange: no pad of their own
     static constexpr uint32_t image_bytes = slab_elems * (((OPT & kOptSplitWord) != 0) ? 4u : 8u);   // one frame's LDS image
     // image word of coefficient e: additive over disjoint bit fields, which is what lets an exchange address
     // register r as (thread base) + compile-time constant

@@ -1,4 +1,4 @@
-// reg_wp.hip -- the wave-packed kernels of the small sizes, n = 32 ... 512, 64-bit arithmetic (wp_kernels.hpp); a group of the kernel
+// reg_wp.hip -- the wave-packed kernels of the small sizes, n = 2 ... 512, 64-bit arithmetic (wp_kernels.hpp); a group of the kernel
 // registry (rb_registry.hpp): ids are stable handles for tests and A/B runs (AGX_VARIANT_REGBLOCK_BASE + id), not indices.
 #define AGX_TU tu_wp
 #include "rb_kernels.hpp"
@@ -24,6 +24,12 @@ const rb_entry kEntries[] = {
     make_entry_wp<8, 4, 1, kWpLazy, 5>(209), make_entry_wp<8, 4, 1, kWpFast, 5>(210), make_entry_wp<8, 4, 1, kWpExact, 5>(211),
     // n = 512: 16 x 32
     make_entry_wp<9, 4, 1, kWpLazy, 5>(212), make_entry_wp<9, 4, 1, kWpFast, 5>(213), make_entry_wp<9, 4, 1, kWpExact, 5>(214),
+    // n = 2 ... 16 (below the reference's size table): ONE LANE per frame -- the whole transform in a lane's registers, every twiddle a scalar, no
+    // exchange at all; 64 frames per wave.  Two forms only (fast for q <= 2^61, else exact): 0.03-0.13 butterflies per byte, nothing to gain from laziness.
+    make_entry_wp<1, 1, 1, kWpFast, 8>(250), make_entry_wp<1, 1, 1, kWpExact, 8>(251),
+    make_entry_wp<2, 2, 1, kWpFast, 8>(252), make_entry_wp<2, 2, 1, kWpExact, 8>(253),
+    make_entry_wp<3, 3, 1, kWpFast, 8>(254), make_entry_wp<3, 3, 1, kWpExact, 8>(255),
+    make_entry_wp<4, 4, 1, kWpFast, 5>(256), make_entry_wp<4, 4, 1, kWpExact, 5>(257),
 #ifdef AGX_DIAG
     // A/B shapes kept in lib/libagxntt_diag.so (measured in profiles/r04_small_sizes_sweeps.txt; 216-219, 223, 225, 226 measured there and deleted)
     make_entry_wp<5, 5, 4, kWpLazy | (kOptSplitWord << 1), 4>(215),      // n = 32: ONE LANE per frame, every twiddle a scalar, split-word image: -5 % forward

@@ -1,5 +1,5 @@
-// wp_kernels.hpp -- "wave-packed" kernels for the small transform sizes, n = 32 ... 512 (n = 32 is the smallest size of the
-// reference's own table, include/kernel/ntt.h:11-12, src/kernel/ntt.cpp:70-71).
+// wp_kernels.hpp -- "wave-packed" kernels for the small transform sizes, n = 2 ... 512 (n = 32 is the smallest size of the
+// reference's own table, include/kernel/ntt.h:11-12, src/kernel/ntt.cpp:70-71; below it one LANE holds a whole frame).
 //
 // A frame of n = 2^L coefficients is held by T = 2^(L-R) lanes with 2^R coefficients each, T < 64: one WAVE carries 64 / T whole
 // frames (n = 32 with R = 5: 64 frames, one per lane) and nothing in a transform ever crosses a wave, so these kernels contain
@@ -29,7 +29,7 @@ enum wp_layout { WP_LANE = 0, WP_PASS0 = 1, WP_LAST = 2 };
 template <int L, int R>
 struct wp_geom {
     static constexpr int C = 1 << R, T = 1 << (L - R), FPW = 64 / T, N = 1 << L;
-    static_assert(L >= 5 && L <= 9 && R <= L && T < 64 && T >= 1, "wave-packed kernels: 32 <= n <= 512, fewer than 64 lanes per frame");
+    static_assert(L >= 1 && L <= 9 && R <= L && T < 64 && T >= 1, "wave-packed kernels: 2 <= n <= 512, fewer than 64 lanes per frame");
     static constexpr bool direct_pass0 = T >= 16;      // pass-0 layout accessed in global memory directly (runs of 8 T bytes per frame)
     // element (within the wave's 64 C coefficients) that `lane` holds in register r under layout LAY: lane part + register part
     template <int LAY>
@@ -169,18 +169,23 @@ __device__ __forceinline__ void wp_store(const uint64_t (&v)[1 << R], uint64_t* 
     constexpr bool NTL = ((ARITH >> 1) & kOptNtLoad) != 0, NTS = ((ARITH >> 1) & kOptNtStore) != 0;  \
     [[maybe_unused]] constexpr bool FASTA = (ARITH & 1) == 1;                                                       \
     constexpr int PADS = F::PADS;                                                                  \
-    unsigned char* wimg = agx_dyn_lds + (size_t)wave * (FPW * F::image_bytes);                     \
+    unsigned char* wimg = agx_dyn_lds + (size_t)wave * wp_wave_image_bytes<L, R, ARITH>();         \
     F f;                                                                                           \
     f.tid = lane % T;                                                                              \
     f.slab = reinterpret_cast<uint64_t*>(wimg + (size_t)(lane / T) * F::image_bytes);              \
     const prime_consts pc = consts[prime];                                                         \
     f.init_consts(pc.q, pc.est)
 
+// one wave's image: its 64 * 2^R coefficients under the padded index E + (E >> PADS) (= 64 / T frames of rb2_frame::image_bytes each once a
+// frame has at least 2^PADS coefficients)
 template <int L, int R, int ARITH>
-constexpr size_t wp_lds_bytes(int wpb) {
+constexpr size_t wp_wave_image_bytes() {
     using F = rb2_frame<L, R, (ARITH & 1) == 1, (ARITH >> 1)>;
-    return (size_t)wpb * wp_geom<L, R>::FPW * F::image_bytes;
+    constexpr size_t words = ((size_t)64 << R) + (((size_t)64 << R) >> F::PADS);
+    return words * (F::SPLIT ? 4 : 8);
 }
+template <int L, int R, int ARITH>
+constexpr size_t wp_lds_bytes(int wpb) { return (size_t)wpb * wp_wave_image_bytes<L, R, ARITH>(); }
 
 template <int L, int R, int WPB, int ARITH, int MINW>
 __global__ void __launch_bounds__(64 * WPB, MINW)
@@ -327,9 +332,12 @@ constexpr rb_entry make_entry_wp(int id) {
 
 // ---- 32-bit arithmetic (every modulus of the plan below 2^31; rb32_kernels.hpp must have been included) ---------------------------
 #ifdef AGX_WP_Q32
+template <int R>
+constexpr size_t wp32_wave_image_words() { return ((size_t)64 << R) + (((size_t)64 << R) >> 5); }      // one pad word per 32, as rb32_frame::img
+
 #define AGX_WP_FRAME32                                                                             \
     using F = rb32_frame<L, R, TIER>;                                                              \
-    uint32_t* wimg = reinterpret_cast<uint32_t*>(agx_dyn_lds) + (size_t)wave * (FPW * F::slab_words);  \
+    uint32_t* wimg = reinterpret_cast<uint32_t*>(agx_dyn_lds) + (size_t)wave * wp32_wave_image_words<R>();  \
     F f;                                                                                           \
     f.tid = lane % T;                                                                              \
     f.slab = wimg + (size_t)(lane / T) * F::slab_words;                                            \
@@ -338,7 +346,7 @@ constexpr rb_entry make_entry_wp(int id) {
     const tw32* tbl = reinterpret_cast<const tw32*>(tw_rb) + (size_t)prime * pairs_per_prime * 2
 
 template <int L, int R>
-constexpr size_t wp32_lds_bytes(int wpb) { return (size_t)wpb * wp_geom<L, R>::FPW * (((size_t)1 << L) + ((size_t)1 << (L - 5))) * 4; }
+constexpr size_t wp32_lds_bytes(int wpb) { return (size_t)wpb * wp32_wave_image_words<R>() * 4; }
 
 // the wave's coefficients in layout LAY as 32-bit values in the transform's entry range (rb32_kernels.hpp: q32_arith::enter)
 template <int L, int R, int LAY, int TIER, bool INVERSE>

@@ -18,7 +18,7 @@ ALL_SIZES = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 
 # only lib/libagxntt_diag.so carries: tests/test_gpu_diag.py re-runs the id-parametrised tests of this file in a child process
 # bound to that library
 PRODUCT_IDS = ({93, 92, 91, 159, 164, 117, 119, 120, 121, 122, 123} | set(range(150, 159)) | set(range(130, 142))
-               | set(range(200, 215)) | set(range(230, 235)) | set(range(240, 245)))
+               | set(range(200, 215)) | set(range(230, 235)) | set(range(240, 245)) | set(range(250, 258)) | set(range(260, 268)))
 
 
 def _select(agx, plan, config):
@@ -54,8 +54,6 @@ def _oracle_forward_rns(orc, x, tabs, n, batch):
 @pytest.mark.parametrize("variant", ["radix2", "regblock"])
 @pytest.mark.parametrize("n", ALL_SIZES)
 def test_forward_bit_exact(agx, orc, dev, n, variant):
-    if variant == "regblock" and n < 32:
-        pytest.skip("register-blocked kernels start at n=32 (wave-packed kernels, csrc/wp_kernels.hpp)")
     bits = 30 if n == 1024 else (61 if n in (8, 8192) else 60)
     batch = 5 if n <= 4096 else 3          # ragged: not a multiple of polys-per-block
     primes = 2 if n <= 8192 else 1
@@ -483,8 +481,10 @@ def test_empty_batch_and_errors(agx, dev):
     with pytest.raises(agx.AgxError) as ei:
         fwd_only.inverse(d.data_ptr(), d.data_ptr(), 1, dev.stream)
     assert ei.value.status == 9
-    # poly-mul: a size without a one-launch kernel (n < 32) needs caller scratch (NULL -> 1), scratch must be distinct (-> 5)
+    # poly-mul: every size has a one-launch kernel now; only a plan forced onto the radix-2 kernels takes the three-launch path and needs
+    # caller scratch (NULL -> 1), which must be disjoint from the operands (-> 5)
     big = agx.Plan(16, [agx.find_primes(60, 16)[0]])
+    big.set_variant(agx.VARIANT_LDS_RADIX2)
     e = dev.empty(512)
     for scratch, status in ((0, 1), (e.data_ptr(), 5)):
         with pytest.raises(agx.AgxError) as ei:
@@ -774,6 +774,9 @@ REGISTRY = [
     (200, 32, 60), (201, 32, 61), (202, 32, 62), (203, 64, 60), (204, 64, 61), (205, 64, 62), (206, 128, 60), (207, 128, 61), (208, 128, 62),
     (209, 256, 60), (210, 256, 61), (211, 256, 62), (212, 512, 60), (213, 512, 61), (214, 512, 62),
     (230, 32, 30), (231, 64, 30), (232, 128, 30), (233, 256, 30), (234, 512, 30), (240, 32, 31), (241, 64, 31), (242, 128, 31), (243, 256, 31), (244, 512, 31),
+    # n = 2 ... 16: one lane per frame (fast / exact; 32-bit tiers)
+    (250, 2, 61), (251, 2, 62), (252, 4, 61), (253, 4, 62), (254, 8, 61), (255, 8, 62), (256, 16, 61), (257, 16, 62),
+    (260, 2, 30), (261, 4, 30), (262, 8, 30), (263, 16, 30), (264, 2, 31), (265, 4, 31), (266, 8, 31), (267, 16, 31),
     # A/B shapes of the wave-packed kernels (lib/libagxntt_diag.so)
     (215, 32, 60), (220, 512, 60), (221, 512, 60), (222, 256, 60), (224, 32, 60), (235, 32, 30), (236, 512, 30),
 ]
@@ -808,13 +811,13 @@ def test_every_registry_entry_at_its_own_size(agx, orc, dev, config, n, max_bits
         plan.close()
 
 
-SMALL_SIZES = [32, 64, 128, 256, 512]
+SMALL_SIZES = [2, 4, 8, 16, 32, 64, 128, 256, 512]
 
 
 @pytest.mark.parametrize("bits", [60, 61, 62, 31, 30, 20])
 @pytest.mark.parametrize("n", SMALL_SIZES)
 def test_wave_packed_small_sizes(agx, orc, dev, n, bits):
-    """n = 32 ... 512 (n = 32 is in the reference's size table, include/kernel/ntt.h:11-12): several frames share a wave
+    """n = 2 ... 512 (n = 32 is in the reference's size table, include/kernel/ntt.h:11-12; below it one lane holds a frame): several frames share a wave
     (csrc/wp_kernels.hpp), so the frame counts here straddle the frames-per-wave and frames-per-workgroup boundaries (a wave whose
     last frames do not exist folds them back for loads and masks their stores).  Forward out of place and in place on inputs in
     [0,4q), lazy outputs, inverse on arbitrary data, extreme coefficients, the one-launch product with every aliasing and NO scratch

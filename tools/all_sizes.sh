@@ -4,7 +4,7 @@
 TAG=${1:-all_sizes}
 OUT=gpurun_out/${TAG}.txt
 : > $OUT
-for n in 32 64 128 256 512 1024 2048 4096 8192 16384 32768; do
+for n in 2 4 8 16 32 64 128 256 512 1024 2048 4096 8192 16384 32768; do
   batch=$(( 1073741824 / 4 / 16 / n ))
   [ $batch -lt 256 ] && batch=256
   for bits in 60 30; do
