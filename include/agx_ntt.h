@@ -156,7 +156,7 @@ AGX_API int agx_ntt_pointwise(const agx_ntt_plan* plan, const uint64_t* d_a, con
                       uint64_t batch, void* stream);
 /* c = a * b in Z_q[X]/(X^n + 1) = INTT(NTT(a) o NTT(b)); dense layout; c may alias a, b or both (squaring in place: a == b == c).
  * d_scratch: num_primes*batch*n elements of device memory owned by the caller, disjoint from a, b, c.
- * Every size has a one-launch fused kernel since round 4, so d_scratch may be NULL; it is only used by plans forced onto the radix-2
+ * Every size has a one-launch fused kernel, so d_scratch may be NULL; it is only used by plans forced onto the radix-2
  * kernels (AGX_VARIANT_LDS_RADIX2: three launches), where a NULL scratch returns AGX_ERR_NULL_POINTER. */
 AGX_API int agx_ntt_polymul(const agx_ntt_plan* plan, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_c,
                     uint64_t* d_scratch, uint64_t batch, void* stream);
